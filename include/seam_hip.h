@@ -1,0 +1,167 @@
+/*
+ * seam_hip.h -- C ABI of libseam_hip.so: the MI355X (gfx950) kernels behind the forward
+ * hot path of SEAM Match-RCNN (BASELINE.json north_star).
+ *
+ * Conventions (every entry point):
+ *   - returns int = hipError_t of the launch (0 = success); never throws, never
+ *     allocates, never synchronises; asynchronous on `stream` (a hipStream_t, e.g.
+ *     torch.cuda.current_stream().cuda_stream passed as void*).
+ *   - all pointers are DEVICE pointers into caller-owned, contiguous fp32 storage
+ *     (int32/int64 where stated); shapes are int32.
+ *   - activations are NHWC ("channels last") fp32 inside the library; the reference's
+ *     NCHW tensors cross the boundary through seam_nchw_to_nhwc_f32 / seam_nhwc_to_nchw_f32.
+ *   - thread-safe for distinct streams.
+ *
+ * Each entry cites the reference interface (file:line under the reference tree) whose
+ * arithmetic it replaces.  "[TV]" = the arithmetic lives in torchvision, which the
+ * reference only configures (models/video_matchrcnn.py:6-9,337-338).
+ */
+#ifndef SEAM_HIP_H
+#define SEAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* seam_stream_t; /* hipStream_t */
+
+/* ABI version (major*1000 + minor). */
+int seam_version(void);
+/* hipGetErrorString for a code returned by any entry point. */
+const char* seam_error_string(int code);
+
+/* ---------------------------------------------------------------------------------
+ * Implicit-GEMM convolution, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces every conv / linear on the path:
+ *   ResNet-50 body + FrozenBN [TV]            (ctor models/video_matchrcnn.py:337)
+ *   FPN lateral/output convs, RPNHead [TV]    (models/video_matchrcnn.py:337-338)
+ *   TwoMLPHead / FastRCNNPredictor [TV]       (call models/video_matchrcnn.py:226-227)
+ *   MaskRCNNHeads / MaskRCNNPredictor [TV]    (call models/video_matchrcnn.py:278-279)
+ *   MatchPredictor.conv_seq / .linear         (models/match_head.py:50-62,67-69,93-95)
+ *
+ *   y[n,ho,wo,k] = act( scale[k] * sum_{r,s,c} x[n,ho*stride+r-pad,wo*stride+s-pad,c]
+ *                                   * w[k][(r*S+s)*C+c]  + shift[k] + residual[n,ho,wo,k] )
+ *
+ * x        NHWC [N,H,W,C], C multiple of 4 (pad channels must be zero-weighted)
+ * w_packed [rows_padded][kred] from seam_pack_conv_weight_f32 (K-contiguous rows)
+ * scale    [K] or NULL (=1);  shift [K] or NULL (=0)   (bias / folded BatchNorm)
+ * residual NHWC [N,Ho,Wo,K] or NULL, added before the activation
+ * relu     0/1
+ * kred     padded reduction length = seam_conv_kred(C,R,S)
+ */
+int seam_conv_kred(int C, int R, int S);           /* host helper: ceil(R*S*C / 32) * 32 */
+int seam_conv_rows_padded(int K);                  /* host helper: ceil(K / 64) * 64      */
+
+/* Pack an OIHW weight [K,Cin,R,S] (PyTorch layout) into [rows_padded][kred] with the
+ * reduction index ordered (r,s,c), c < Cstore (channels >= Cin zero-filled).
+ * mode 0: Conv2d / Linear (Linear = R=S=1; fc6 = a 7x7 "valid" conv over the 7x7 ROI tile)
+ * mode 1: ConvTranspose2d(k=2,s=2) weight [Cin,Cout,2,2] -> rows ((a*2+b)*Cout + co),
+ *         i.e. a 1x1 conv producing the 4 sub-pixels as channel groups; K = 4*Cout.   */
+int seam_pack_conv_weight_f32(const float* w, float* w_packed, int K, int Cin, int R, int S,
+                              int Cstore, int mode, seam_stream_t stream);
+
+int seam_conv2d_f32(const float* x, const float* w_packed, const float* scale,
+                    const float* shift, const float* residual, float* y,
+                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                    int relu, seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * GeneralizedRCNNTransform [TV] (reached from GeneralizedRCNN.forward; callers
+ * stuffs/engine.py:115, evaluate_movingfashion.py:31): per image
+ *   (x-mean)/std -> bilinear resize (align_corners=False, scale=in/out) to [out_h,out_w]
+ *   -> zero-pad to [Hp,Wp] -> NHWC with 4 stored channels (4th = 0).
+ * img  CHW [3,in_h,in_w] in [0,1];  out NHWC4 slot [Hp,Wp,4] of the batch tensor. */
+int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int out_h, int out_w,
+                        int Hp, int Wp, seam_stream_t stream);
+
+/* max_pool2d on NHWC [TV: ResNet stem 3x3/s2/p1; LastLevelMaxPool k=1,s=2]. C % 4 == 0. */
+int seam_maxpool2d_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride,
+                       int pad, seam_stream_t stream);
+
+/* FPN top-down [TV]: lat[n,h,w,:] += top[n, floor(h*Ht/H), floor(w*Wt/W), :] (nearest). */
+int seam_upsample_add_f32(float* lat, const float* top, int N, int H, int W, int Ht, int Wt, int C,
+                          seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * MultiScaleRoIAlign(['0','1','2','3'], P, sampling_ratio) + roi_align(aligned=False) [TV]
+ * call sites models/video_matchrcnn.py:225 (P=7), :277 (P=14); models/matchrcnn.py:463.
+ * feat[l] NHWC [N,Hl,Wl,C] (C % 4 == 0, C <= 1024);  rois [K,5] = (batch_idx,x1,y1,x2,y2)
+ * in resized-image pixels;  levels int32 [K] or NULL (NULL: LevelMapper on device:
+ * clamp(floor(4+log2(sqrt(area)/224)+1e-6), k_min, k_min+3) - k_min);
+ * scales[l] = 2^round(log2(Hl/Himg)) passed by value;  out NHWC [K,P,P,C]. */
+int seam_roi_align_f32(const float* feat0, const float* feat1, const float* feat2, const float* feat3,
+                       const int* hw /* host int[8]: H0,W0,...,H3,W3 */, int C,
+                       float scale0, float scale1, float scale2, float scale3, int k_min,
+                       const float* rois, const int* levels, float* out, int K, int P,
+                       int sampling_ratio, seam_stream_t stream);
+
+/* Layout bridges at the module boundary: x [B,C,L] <-> y [B,L,C]. */
+int seam_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int L, seam_stream_t stream);
+int seam_nhwc_to_nchw_f32(const float* x, float* y, int B, int L, int C, seam_stream_t stream);
+
+/* AvgPool2d((6,6)) (+ no-op ReLU) of models/match_head.py:59-60: x [K,L,C] -> y [K,C]. */
+int seam_avgpool_f32(const float* x, float* y, int K, int L, int C, seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * NONLocalBlock1D(256, sub_sample=False, bn_layer=False) + attention pooling, batched
+ * over sequences: models/nlb.py:66-101 via models/match_head.py:114-121 / :144-151.
+ *   per sequence X[T,256]:  TH/PH/G = X W^T + b ; a = TH.wc[:128] ; b = PH.wc[128:]
+ *   f = ReLU(a_i+b_j)/T ; Y = f G ; Z = Y Ww^T + bw + X      (T == 1: Z = X, ref :115-117)
+ *   s = Z.wa + ba ; p = softmax_t(s) ; out = sum_t p_t Z_t   (T == 0: out = 0)
+ * seq      element (t,s,c) at seq[t*t_stride + s*s_stride + c], t < len[s]
+ *          (pass x3_1_seq + S*256, t_stride = S*256, s_stride = 256: row 0 is the dummy)
+ * len      int32 [S] (device)
+ * w_proj_t [256][384] = concat(theta,phi,g).weight transposed;  b_proj [384]
+ * w_cat    [256] concat_project weight;  w_out_t [128][256] = W.weight^T;  b_out [256]
+ * w_att [256], b_att [1]
+ * out [S,256];  att [S,Tmax] or NULL (softmax weights; entries >= len[s] untouched)
+ * z   [S,Tmax,256] or NULL: the non-local block's own output Z (= NONLocalBlock1D.forward)
+ * ws   workspace, >= seam_nlb_workspace_floats(S,Tmax) floats
+ * use_nlb  0: no block; 1: the module's `.nlb` flag (models/match_head.py:88), length-1
+ *          sequences bypass the block (ref :115-117); 2: apply the block to every sequence */
+int64_t seam_nlb_workspace_floats(int S, int Tmax);
+int seam_nlb_attnpool_f32(const float* seq, int64_t t_stride, int64_t s_stride, const int* len,
+                          int S, int Tmax, const float* w_proj_t, const float* b_proj,
+                          const float* w_cat, const float* w_out_t, const float* b_out,
+                          const float* w_att, const float* b_att, float* out, float* att,
+                          float* z, float* ws, int use_nlb, seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Pairwise match classifier `last((a_i - b_j)^2)`: models/match_head.py:73-74,161-162;
+ * NumPy twin evaluate_movingfashion.py:94-100,263-264.
+ * a [Q,D], b [G,D], w [2,D], bias [2] -> out [Q,G,2].   D % 32 == 0, D <= 1024. */
+int seam_pair_logits_f32(const float* a, const float* b, const float* w, const float* bias,
+                         float* out, int Q, int G, int D, seam_stream_t stream);
+
+/* Score + rank: evaluate_movingfashion.py:97-99,265-269.  Reads logits [Q,G,2]; ranks by
+ * softmax(x)[...,1] (== monotone in x1-x0), descending, ties -> lower index first.
+ * idx int64 [Q,k], score [Q,k] = softmax(x)[...,1] of the selected entries. k <= G. */
+int seam_rank_topk_f32(const float* logits, int64_t* idx, float* score, int Q, int G, int k,
+                       seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Detection post-processing [TV] + models/video_matchrcnn.py:154-205.
+ * BoxCoder.decode (weights wx,wy,ww,wh; dw,dh clamped to log(1000/16)) + clip to image.
+ * deltas [N,ncls*4], anchors/proposals [N,4] -> boxes [N,ncls*4]. */
+int seam_decode_boxes_f32(const float* deltas, const float* boxes_in, float* boxes_out, int N,
+                          int ncls, float wx, float wy, float ww, float wh, float clip_h,
+                          float clip_w, seam_stream_t stream);
+
+/* Greedy NMS over boxes ALREADY SORTED by descending score: keep[i]=1/0 (int32 [N]).
+ * IoU > thr suppresses (strict), areas without +1.  Bitmask formulation, N <= 8192.
+ * mask_ws: uint64 workspace of N*ceil(N/64) words. */
+int seam_nms_sorted_f32(const float* boxes, int* keep, int N, float thr, uint64_t* mask_ws,
+                        seam_stream_t stream);
+
+/* maskrcnn_inference [TV] (call models/video_matchrcnn.py:291): logits laid out
+ * [K,14,14,(a,b),ncls] (sub-pixel groups from the transposed conv) -> prob [K,1,28,28] of the
+ * channel labels[k] (int64), after sigmoid. */
+int seam_mask_select_f32(const float* logits, const int64_t* labels, float* prob, int K, int ncls,
+                         seam_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEAM_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of ``lib/libseam_hip.so`` (the C ABI declared in ``include/seam_hip.h``).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing/using the product path raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C seam-match-rcnn_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libseam_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); mirrors include/seam_hip.h one to one
+SIGNATURES = {
+    "seam_version": (_i, []),
+    "seam_error_string": (C.c_char_p, [_i]),
+    "seam_conv_kred": (_i, [_i, _i, _i]),
+    "seam_conv_rows_padded": (_i, [_i]),
+    "seam_pack_conv_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv2d_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_preprocess_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_maxpool2d_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_upsample_add_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_roi_align_f32": (_i, [_p, _p, _p, _p, C.POINTER(_i), _i, _f, _f, _f, _f, _i, _p, _p, _p, _i, _i, _i, _p]),
+    "seam_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "seam_nhwc_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "seam_avgpool_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "seam_nlb_workspace_floats": (_i64, [_i, _i]),
+    "seam_nlb_attnpool_f32": (_i, [_p, _i64, _i64, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "seam_pair_logits_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "seam_rank_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "seam_decode_boxes_f32": (_i, [_p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _p]),
+    "seam_nms_sorted_f32": (_i, [_p, _p, _i, _f, _p, _p]),
+    "seam_mask_select_f32": (_i, [_p, _p, _p, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class SeamNativeError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the bound library; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SeamNativeError(
+            f"{LIB_PATH} not found: the HIP extension is required (there is no CPU/PyTorch fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:   # e.g. libamdhip64 missing
+        raise SeamNativeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise SeamNativeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().seam_error_string(code)
+        raise SeamNativeError(f"{what} failed: hipError {code} ({msg.decode() if msg else '?'})")

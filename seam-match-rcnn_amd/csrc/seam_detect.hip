@@ -1,0 +1,137 @@
+// seam_detect.hip -- detection post-processing kernels (gfx950): BoxCoder.decode + clip, greedy NMS
+// (64x64 bitmask tiles + one-wave scan), mask-channel select.  Latency-bound integer/bit work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr float kXformClip = 4.135166556742356f;   // log(1000/16)
+
+__global__ void decode_boxes_kernel(const float* __restrict__ deltas, const float* __restrict__ boxes,
+                                    float* __restrict__ out, int N, int ncls, float wx, float wy, float ww, float wh,
+                                    float clip_h, float clip_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * ncls) return;
+    const int n = i / ncls;
+    const float4 bx = reinterpret_cast<const float4*>(boxes)[n];
+    const float4 d = reinterpret_cast<const float4*>(deltas)[i];
+    const float w = bx.z - bx.x, h = bx.w - bx.y;
+    const float cx = bx.x + 0.5f * w, cy = bx.y + 0.5f * h;
+    const float dx = d.x / wx, dy = d.y / wy;
+    const float dw = fminf(d.z / ww, kXformClip), dh = fminf(d.w / wh, kXformClip);
+    const float pcx = dx * w + cx, pcy = dy * h + cy;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+    if (clip_w > 0.f) {
+        x1 = fminf(fmaxf(x1, 0.f), clip_w); x2 = fminf(fmaxf(x2, 0.f), clip_w);
+        y1 = fminf(fmaxf(y1, 0.f), clip_h); y2 = fminf(fmaxf(y2, 0.f), clip_h);
+    }
+    reinterpret_cast<float4*>(out)[i] = make_float4(x1, y1, x2, y2);
+}
+
+// mask[i][jb] bit j: box (jb*64+j) overlaps box i with IoU > thr (only j > i matters)
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, uint64_t* __restrict__ mask,
+                                                      int N, float thr) {
+    const int ib = blockIdx.y, jb = blockIdx.x;
+    if (jb < ib) return;
+    __shared__ float4 cb[64];
+    const int t = threadIdx.x;
+    const int j = jb * 64 + t;
+    if (j < N) cb[t] = reinterpret_cast<const float4*>(boxes)[j];
+    __syncthreads();
+    const int i = ib * 64 + t;
+    if (i >= N) return;
+    const float4 a = reinterpret_cast<const float4*>(boxes)[i];
+    const float aa = (a.z - a.x) * (a.w - a.y);
+    const int nj = min(64, N - jb * 64);
+    uint64_t bits = 0;
+    for (int k = (ib == jb ? t + 1 : 0); k < nj; ++k) {
+        const float4 c = cb[k];
+        const float w = fmaxf(fminf(a.z, c.z) - fmaxf(a.x, c.x), 0.f);
+        const float h = fmaxf(fminf(a.w, c.w) - fmaxf(a.y, c.y), 0.f);
+        const float inter = w * h;
+        const float iou = inter / (aa + (c.z - c.x) * (c.w - c.y) - inter);
+        if (iou > thr) bits |= 1ull << k;
+    }
+    mask[(size_t)i * gridDim.x + jb] = bits;
+}
+
+// one wave: walk the 64-box blocks in order; resolve each diagonal block with scalar bit ops, then
+// OR the kept rows into the running "removed" words (lane l owns words l, l+64, ... of <= 128 words).
+__global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict__ mask, int* __restrict__ keep,
+                                                      int N, int nb) {
+    const int lane = threadIdx.x;
+    uint64_t rem0 = 0, rem1 = 0;   // removed bits of words lane, lane+64
+    for (int blk = 0; blk < nb; ++blk) {
+        // removed word of this block lives in lane (blk & 63), slot (blk >> 6)
+        const uint64_t mine = (blk >> 6) ? rem1 : rem0;
+        uint64_t removed = __shfl(mine, blk & 63, 64);
+        const int i = blk * 64 + lane;
+        const uint64_t diag = i < N ? mask[(size_t)i * nb + blk] : 0ull;
+        const int nvalid = min(64, N - blk * 64);
+        uint64_t kept = 0;
+        for (int b = 0; b < nvalid; ++b) {
+            const uint64_t row = __shfl(diag, b, 64);     // wave-uniform
+            if (!((removed >> b) & 1ull)) {
+                kept |= 1ull << b;
+                removed |= row;
+            }
+        }
+        if (i < N) keep[i] = (int)((kept >> lane) & 1ull);
+        // propagate kept rows to later words
+        uint64_t kk = kept;
+        while (kk) {
+            const int b = __ffsll((unsigned long long)kk) - 1;
+            kk &= kk - 1;
+            const size_t rowoff = (size_t)(blk * 64 + b) * nb;
+            if (lane > blk && lane < nb) rem0 |= mask[rowoff + lane];
+            if (lane + 64 > blk && lane + 64 < nb) rem1 |= mask[rowoff + lane + 64];
+        }
+    }
+}
+
+// logits [K,14,14,4,ncls] (sub-pixel (a,b) groups) -> prob [K,1,28,28], channel labels[k]
+__global__ void mask_select_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                   float* __restrict__ prob, int K, int ncls) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * 784) return;
+    const int k = i / 784;
+    const int r = i - k * 784;
+    const int y = r / 28, x = r - y * 28;
+    const int h = y >> 1, a = y & 1, w = x >> 1, b = x & 1;
+    const int lab = (int)labels[k];
+    const float v = logits[((((size_t)k * 14 + h) * 14 + w) * 4 + (a * 2 + b)) * ncls + lab];
+    prob[i] = 1.f / (1.f + expf(-v));
+}
+
+}  // namespace
+
+extern "C" {
+
+int seam_decode_boxes_f32(const float* deltas, const float* boxes_in, float* boxes_out, int N, int ncls, float wx,
+                          float wy, float ww, float wh, float clip_h, float clip_w, void* stream) {
+    if (N <= 0) return 0;
+    const int total = N * ncls;
+    hipLaunchKernelGGL(decode_boxes_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, deltas,
+                       boxes_in, boxes_out, N, ncls, wx, wy, ww, wh, clip_h, clip_w);
+    return (int)hipGetLastError();
+}
+
+int seam_nms_sorted_f32(const float* boxes, int* keep, int N, float thr, uint64_t* mask_ws, void* stream) {
+    if (N <= 0) return 0;
+    if (N > 8192) return (int)hipErrorInvalidValue;
+    const int nb = (N + 63) / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, (hipStream_t)stream, boxes, mask_ws, N, thr);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mask_ws, keep, N, nb);
+    return (int)hipGetLastError();
+}
+
+int seam_mask_select_f32(const float* logits, const int64_t* labels, float* prob, int K, int ncls, void* stream) {
+    if (K <= 0) return 0;
+    const int total = K * 784;
+    hipLaunchKernelGGL(mask_select_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits,
+                       labels, prob, K, ncls);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// seam_elementwise.hip -- HBM-bound glue kernels of the path (NHWC fp32, 16 B per lane).
+//   preprocess   GeneralizedRCNNTransform: normalise + bilinear resize + pad + CHW->NHWC4
+//   maxpool2d    ResNet stem pool / FPN LastLevelMaxPool
+//   upsample_add FPN top-down merge (nearest)
+//   transposes   NCHW <-> NHWC bridges at the module boundary (LDS-tiled, both sides coalesced)
+//   avgpool      AvgPool2d((6,6)) of the match trunk
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void bilinear_axis(int dst, int in, int out, int& i0, int& i1, float& l1) {
+    // ATen upsample_bilinear2d, align_corners=False, scale = in/out (recompute_scale_factor=True)
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    int i = (int)src;
+    if (i > in - 1) i = in - 1;
+    i0 = i;
+    i1 = (i < in - 1) ? i + 1 : i;
+    float l = src - (float)i;
+    l1 = fminf(fmaxf(l, 0.f), 1.f);
+}
+
+__global__ void preprocess_kernel(const float* __restrict__ img, float* __restrict__ out, int in_h, int in_w,
+                                  int out_h, int out_w, int Hp, int Wp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= Wp) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y < out_h && x < out_w) {
+        const float mean[3] = {0.485f, 0.456f, 0.406f};
+        const float stdv[3] = {0.229f, 0.224f, 0.225f};
+        if (out_h == in_h && out_w == in_w) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = (img[((size_t)c * in_h + y) * in_w + x] - mean[c]) / stdv[c];
+        } else {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilinear_axis(y, in_h, out_h, y0, y1, ly);
+            bilinear_axis(x, in_w, out_w, x0, x1, lx);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* p = img + (size_t)c * in_h * in_w;
+                const float v00 = (p[(size_t)y0 * in_w + x0] - mean[c]) / stdv[c];
+                const float v01 = (p[(size_t)y0 * in_w + x1] - mean[c]) / stdv[c];
+                const float v10 = (p[(size_t)y1 * in_w + x0] - mean[c]) / stdv[c];
+                const float v11 = (p[(size_t)y1 * in_w + x1] - mean[c]) / stdv[c];
+                v[c] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + ((size_t)y * Wp + x) * 4) = v;
+}
+
+__global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                               int Ho, int Wo, int k, int stride, int pad) {
+    const int c4 = C >> 2;
+    const size_t total = (size_t)N * Ho * Wo * c4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4);
+        size_t r = i / c4;
+        const int wo = (int)(r % Wo);
+        r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int a = 0; a < k; ++a) {
+            const int hi = ho * stride - pad + a;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int b = 0; b < k; ++b) {
+                const int wi = wo * stride - pad + b;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + hi) * W + wi) * C + c * 4);
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]);
+                m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = m;
+    }
+}
+
+__global__ void upsample_add_kernel(float* __restrict__ lat, const float* __restrict__ top, int N, int H, int W,
+                                    int Ht, int Wt, int C) {
+    const int c4 = C >> 2;
+    const size_t total = (size_t)N * H * W * c4;
+    const float sh = (float)Ht / (float)H, sw = (float)Wt / (float)W;   // ATen nearest: floor(dst*scale)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4);
+        size_t r = i / c4;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        int ht = (int)floorf((float)h * sh);
+        int wt = (int)floorf((float)w * sw);
+        if (ht > Ht - 1) ht = Ht - 1;
+        if (wt > Wt - 1) wt = Wt - 1;
+        f32x4 a = *reinterpret_cast<f32x4*>(lat + i * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(top + (((size_t)n * Ht + ht) * Wt + wt) * C + c * 4);
+        a += b;
+        *reinterpret_cast<f32x4*>(lat + i * 4) = a;
+    }
+}
+
+// y[b][j][i] = x[b][i][j]; x is [B][rows][cols]
+__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const size_t boff = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int r = r0 + ty + k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + k][tx] = x[boff + (size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int c = c0 + ty + k, r = r0 + tx;
+        if (r < rows && c < cols) y[boff + (size_t)c * rows + r] = tile[tx][ty + k];
+    }
+}
+
+__global__ void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int K, int L, int C) {
+    const size_t total = (size_t)K * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t k = i / C;
+        const float* p = x + k * L * C + c;
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += p[(size_t)l * C];
+        y[i] = s / (float)L;
+    }
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
+    size_t g = (total + block - 1) / block;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp,
+                        void* stream) {
+    dim3 grid((Wp + 255) / 256, Hp);
+    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, out, in_h, in_w, out_h,
+                       out_w, Hp, Wp);
+    return (int)hipGetLastError();
+}
+
+int seam_maxpool2d_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad,
+                       void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C >> 2);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C,
+                       Ho, Wo, k, stride, pad);
+    return (int)hipGetLastError();
+}
+
+int seam_upsample_add_f32(float* lat, const float* top, int N, int H, int W, int Ht, int Wt, int C, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)N * H * W * (C >> 2);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, lat, top, N,
+                       H, W, Ht, Wt, C);
+    return (int)hipGetLastError();
+}
+
+// x [B,C,L] -> y [B,L,C]
+int seam_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int L, void* stream) {
+    dim3 grid((L + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, L);
+    return (int)hipGetLastError();
+}
+
+// x [B,L,C] -> y [B,C,L]
+int seam_nhwc_to_nchw_f32(const float* x, float* y, int B, int L, int C, void* stream) {
+    dim3 grid((C + 31) / 32, (L + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, L, C);
+    return (int)hipGetLastError();
+}
+
+int seam_avgpool_f32(const float* x, float* y, int K, int L, int C, void* stream) {
+    hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for((size_t)K * C)), dim3(256), 0, (hipStream_t)stream, x, y, K,
+                       L, C);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,479 @@
+"""The torchvision-owned stages of the path, rebuilt on the gfx950 kernels.
+
+The reference contains no arithmetic for these (it configures ``torchvision`` objects:
+ref models/video_matchrcnn.py:6-9,337-338; models/matchrcnn.py:2-3,11-28); this module
+supplies them with torchvision's classic (<=0.12) module/attribute/state-dict names
+ so reference checkpoints load unchanged:
+
+  GeneralizedRCNNTransform   normalise / resize / pad / batch            (row a2)
+  ResNet50Body + FPN         ``backbone.body.*``, ``backbone.fpn.*``         (rows a3, a4)
+  RegionProposalNetwork      ``rpn.head.*`` + anchors + filter_proposals   (row a5)
+  MultiScaleRoIAlign         FPN level mapper + RoIAlign                 (row a7)
+  TwoMLPHead / FastRCNNPredictor / MaskRCNNHeads / MaskRCNNPredictor     (rows a6, a8)
+
+Activations are NHWC fp32 device tensors internally.  Modules hold parameters only
+(``nn.Conv2d`` etc. as containers); every ``forward`` launches HIP kernels through
+``ops`` -- CPU tensors raise, there is no eager fallback.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+
+RESNET50_LAYERS = ((3, 64, 1), (4, 128, 2), (6, 256, 2), (3, 512, 2))
+BBOX_XFORM_CLIP = math.log(1000.0 / 16)
+
+
+def _key(params) -> tuple:
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+# ------------------------------------------------------------------------------ transform (a2)
+def resized_size(h: int, w: int, min_size: int = 800, max_size: int = 1333) -> Tuple[int, int, float]:
+    """scale = min(min_size/min(h,w), max_size/max(h,w)); out = floor(in*scale)
+    (torchvision ``_resize_image_and_masks`` with ``recompute_scale_factor=True``)."""
+    scale = min(float(min_size) / float(min(h, w)), float(max_size) / float(max(h, w)))
+    return int(math.floor(float(h) * scale)), int(math.floor(float(w) * scale)), scale
+
+
+class GeneralizedRCNNTransform(nn.Module):
+    def __init__(self, min_size=800, max_size=1333, size_divisible=32):
+        super().__init__()
+        self.min_size, self.max_size, self.size_divisible = min_size, max_size, size_divisible
+
+    def forward(self, images: Sequence[torch.Tensor]):
+        """list of [3,H,W] in [0,1] -> (NHWC4 batch [N,Hp,Wp,4], image_sizes, original_sizes)."""
+        orig = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]
+        sizes = [resized_size(h, w, self.min_size, self.max_size)[:2] for h, w in orig]
+        d = self.size_divisible
+        hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
+        wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
+        return ops.preprocess(images, sizes, hp, wp), sizes, orig
+
+    @staticmethod
+    def rescale_boxes(boxes: torch.Tensor, from_hw, to_hw) -> torch.Tensor:
+        rh, rw = float(to_hw[0]) / float(from_hw[0]), float(to_hw[1]) / float(from_hw[1])
+        return boxes * boxes.new_tensor([rw, rh, rw, rh])
+
+
+# ------------------------------------------------------------------------------ backbone (a3)
+class FrozenBatchNorm2d(nn.Module):
+    """Buffers only (weight, bias, running_mean, running_var); folded into the conv epilogue."""
+
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def tensors(self):
+        return (self.weight, self.bias, self.running_mean, self.running_var)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = FrozenBatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)     # v1.5: stride on the 3x3
+        self.bn2 = FrozenBatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(planes * 4)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False),
+                                            FrozenBatchNorm2d(planes * 4))
+        self.stride = stride
+
+
+class ResNet50Body(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(64)
+        inpl = 64
+        for li, (nblk, planes, stride) in enumerate(RESNET50_LAYERS, start=1):
+            blocks = []
+            for bi in range(nblk):
+                blocks.append(Bottleneck(inpl, planes, stride if bi == 0 else 1, bi == 0))
+                inpl = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self._pk, self._pk_key = None, None
+
+    def _all(self):
+        return list(self.parameters()) + list(self.buffers())
+
+    def packed(self):
+        key = _key(self._all())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                pk = {"stem": ops.pack_conv(self.conv1.weight, None, self.bn1.tensors(), stride=2, pad=3, cstore=4,
+                                            bn_eps=self.bn1.eps)}
+                for li in range(1, 5):
+                    for bi, b in enumerate(getattr(self, f"layer{li}")):
+                        e = {"c1": ops.pack_conv(b.conv1.weight, None, b.bn1.tensors(), bn_eps=b.bn1.eps),
+                             "c2": ops.pack_conv(b.conv2.weight, None, b.bn2.tensors(), stride=b.stride, pad=1,
+                                                 bn_eps=b.bn2.eps),
+                             "c3": ops.pack_conv(b.conv3.weight, None, b.bn3.tensors(), bn_eps=b.bn3.eps)}
+                        if b.downsample is not None:
+                            e["ds"] = ops.pack_conv(b.downsample[0].weight, None, b.downsample[1].tensors(),
+                                                    stride=b.stride, bn_eps=b.downsample[1].eps)
+                        pk[(li, bi)] = e
+            self._pk, self._pk_key = pk, key
+        return self._pk
+
+    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """x NHWC4 [N,H,W,4] -> [C2, C3, C4, C5] NHWC."""
+        pk = self.packed()
+        x = ops.conv2d(x, pk["stem"], relu=True)               # 7x7/s2 + FrozenBN + ReLU
+        x = ops.maxpool2d(x, 3, 2, 1)
+        feats = []
+        for li in range(1, 5):
+            for bi in range(len(getattr(self, f"layer{li}"))):
+                e = pk[(li, bi)]
+                o = ops.conv2d(x, e["c1"], relu=True)
+                o = ops.conv2d(o, e["c2"], relu=True)
+                idt = ops.conv2d(x, e["ds"]) if "ds" in e else x
+                x = ops.conv2d(o, e["c3"], relu=True, residual=idt)   # bn3 + add + ReLU fused
+            feats.append(x)
+        return feats
+
+
+class FeaturePyramidNetwork(nn.Module):
+    def __init__(self, in_channels=(256, 512, 1024, 2048), out_channels=256):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList([nn.Conv2d(c, out_channels, 1) for c in in_channels])
+        self.layer_blocks = nn.ModuleList([nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels])
+        self._pk, self._pk_key = None, None
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        # torchvision >= 0.13 wraps the convs in Conv2dNormActivation: ``inner_blocks.{i}.0.weight``
+        for key in [k_ for k_ in state_dict if k_.startswith(prefix)]:
+            parts = key[len(prefix):].split(".")
+            if len(parts) == 4 and parts[0] in ("inner_blocks", "layer_blocks") and parts[2] == "0":
+                state_dict[prefix + ".".join((parts[0], parts[1], parts[3]))] = state_dict.pop(key)
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def packed(self):
+        key = _key(self.parameters())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                self._pk = ([ops.pack_conv(m.weight, m.bias) for m in self.inner_blocks],
+                            [ops.pack_conv(m.weight, m.bias, pad=1) for m in self.layer_blocks])
+            self._pk_key = key
+        return self._pk
+
+    def forward(self, feats: List[torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+        inner, layer = self.packed()
+        last = ops.conv2d(feats[3], inner[3])
+        outs = [None, None, None, ops.conv2d(last, layer[3])]
+        for i in (2, 1, 0):
+            lat = ops.conv2d(feats[i], inner[i])
+            last = ops.upsample_add_(lat, last)               # nearest top-down merge, in place
+            outs[i] = ops.conv2d(last, layer[i])
+        od = OrderedDict((str(i), o) for i, o in enumerate(outs))
+        od["pool"] = ops.maxpool2d(outs[3], 1, 2, 0)          # LastLevelMaxPool
+        return od
+
+
+class BackboneWithFPN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.body = ResNet50Body()
+        self.fpn = FeaturePyramidNetwork()
+        self.out_channels = 256
+
+    def forward(self, x):
+        return self.fpn(self.body(x))
+
+
+def resnet_fpn_backbone(backbone_name="resnet50", pretrained=False, **_):
+    if backbone_name != "resnet50":
+        raise NotImplementedError("only resnet50 is on the SEAM path (ref models/video_matchrcnn.py:337)")
+    if pretrained:
+        import warnings
+        warnings.warn("pretrained_backbone=True ignored: no network in this environment; load weights with "
+                      "load_state_dict() (keys are torchvision-compatible)")
+    return BackboneWithFPN()
+
+
+# ------------------------------------------------------------------------------ RPN (a5)
+class RPNHead(nn.Module):
+    def __init__(self, in_channels=256, num_anchors=3):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, padding=1)
+        self.cls_logits = nn.Conv2d(in_channels, num_anchors, 1)
+        self.bbox_pred = nn.Conv2d(in_channels, num_anchors * 4, 1)
+        self.num_anchors = num_anchors
+        self._pk, self._pk_key = None, None
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        old = prefix + "conv.0.0."           # torchvision >= 0.13 layout
+        for s in ("weight", "bias"):
+            if old + s in state_dict:
+                state_dict[prefix + "conv." + s] = state_dict.pop(old + s)
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def packed(self):
+        key = _key(self.parameters())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                w = torch.cat([self.cls_logits.weight, self.bbox_pred.weight], 0)       # A + 4A rows, one launch
+                b = torch.cat([self.cls_logits.bias, self.bbox_pred.bias], 0)
+                self._pk = (ops.pack_conv(self.conv.weight, self.conv.bias, pad=1), ops.pack_conv(w, b))
+            self._pk_key = key
+        return self._pk
+
+    def forward(self, feats: Sequence[torch.Tensor]):
+        """-> per level ([N,H,W,A] objectness, [N,H,W,4A] deltas), NHWC == torchvision's
+        permute(0,2,3,1) order (h, w, anchor[, coord])."""
+        conv, heads = self.packed()
+        a = self.num_anchors
+        out = []
+        for f in feats:
+            o = ops.conv2d(ops.conv2d(f, conv, relu=True), heads)
+            out.append((o[..., :a], o[..., a:]))
+        return out
+
+
+def _base_anchors(size: float, ratios=(0.5, 1.0, 2.0)) -> np.ndarray:
+    r = np.asarray(ratios, dtype=np.float32)
+    h_r = np.sqrt(r)
+    w_r = (np.float32(1.0) / h_r).astype(np.float32)
+    ws = (w_r * np.float32(size)).astype(np.float32)
+    hs = (h_r * np.float32(size)).astype(np.float32)
+    return np.round(np.stack([-ws, -hs, ws, hs], 1) / np.float32(2.0)).astype(np.float32)   # half-to-even
+
+
+def grid_anchors(padded_hw, feat_hws, sizes=(32, 64, 128, 256, 512)) -> List[np.ndarray]:
+    """AnchorGenerator: stride = padded_size // feature_size (integer division: 800//13 = 61);
+    order (y, x, anchor)."""
+    out = []
+    for (fh, fw), s in zip(feat_hws, sizes):
+        sh, sw = padded_hw[0] // fh, padded_hw[1] // fw
+        xs = (np.arange(fw, dtype=np.float32) * np.float32(sw))
+        ys = (np.arange(fh, dtype=np.float32) * np.float32(sh))
+        yy, xx = np.meshgrid(ys, xs, indexing="ij")
+        sh4 = np.stack([xx.ravel(), yy.ravel(), xx.ravel(), yy.ravel()], 1)
+        out.append((sh4[:, None, :] + _base_anchors(s)[None]).reshape(-1, 4).astype(np.float32))
+    return out
+
+
+def batched_nms(boxes, scores, idxs, thr):
+    """torchvision ``batched_nms`` (coordinate-offset form) -> kept indices by descending score.
+    The IoU/suppression bit-matrix and the greedy scan are HIP kernels; the sort is a device sort."""
+    if boxes.numel() == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
+    off = idxs.to(boxes) * (boxes.max() + 1.0)
+    order = torch.argsort(scores, descending=True, stable=True)
+    keep = ops.nms_sorted((boxes + off[:, None])[order].contiguous(), thr)
+    return order[keep.bool()]
+
+
+class RegionProposalNetwork(nn.Module):
+    def __init__(self, pre_nms_top_n_test=1000, post_nms_top_n_test=1000, nms_thresh=0.7, min_size=1e-3,
+                 pre_nms_top_n_train=2000, post_nms_top_n_train=2000):
+        super().__init__()
+        self.head = RPNHead()
+        self.pre_nms_top_n, self.post_nms_top_n = pre_nms_top_n_test, post_nms_top_n_test
+        self.nms_thresh, self.min_size = nms_thresh, min_size
+        self._anchor_cache = {}
+
+    def anchors(self, padded_hw, feat_hws, device):
+        key = (tuple(padded_hw), tuple(map(tuple, feat_hws)), str(device))
+        if key not in self._anchor_cache:
+            self._anchor_cache[key] = [torch.from_numpy(a).to(device) for a in grid_anchors(padded_hw, feat_hws)]
+        return self._anchor_cache[key]
+
+    def forward(self, feats: "OrderedDict[str, torch.Tensor]", image_sizes, padded_hw):
+        fl = list(feats.values())
+        head = self.head(fl)
+        n = fl[0].shape[0]
+        anchors = self.anchors(padded_hw, [f.shape[1:3] for f in fl], fl[0].device)
+        props = []
+        for b in range(n):                                      # RegionProposalNetwork.filter_proposals
+            bx, sc, lv = [], [], []
+            for l, ((obj, dlt), anc) in enumerate(zip(head, anchors)):
+                o = obj[b].reshape(-1)
+                k = min(self.pre_nms_top_n, o.numel())
+                top = torch.argsort(o, descending=True, stable=True)[:k]    # ties -> lower index
+                d = dlt[b].reshape(-1, 4)[top].contiguous()
+                bx.append(ops.decode_boxes(d, anc[top].contiguous(), (1.0, 1.0, 1.0, 1.0), image_sizes[b]))
+                sc.append(torch.sigmoid(o[top]))
+                lv.append(torch.full((k,), l, dtype=torch.int64, device=o.device))
+            bx, sc, lv = torch.cat(bx), torch.cat(sc), torch.cat(lv)
+            keep = ((bx[:, 2] - bx[:, 0]) >= self.min_size) & ((bx[:, 3] - bx[:, 1]) >= self.min_size)
+            bx, sc, lv = bx[keep], sc[keep], lv[keep]
+            keep = batched_nms(bx, sc, lv, self.nms_thresh)[:self.post_nms_top_n]
+            props.append(bx[keep])
+        return props
+
+
+# ------------------------------------------------------------------------------ RoIAlign (a7)
+class MultiScaleRoIAlign(nn.Module):
+    def __init__(self, featmap_names=("0", "1", "2", "3"), output_size=7, sampling_ratio=2):
+        super().__init__()
+        self.featmap_names = list(featmap_names)
+        self.output_size = output_size if isinstance(output_size, int) else output_size[0]
+        self.sampling_ratio = sampling_ratio
+
+    @staticmethod
+    def infer_scales(feat_hws, image_sizes):
+        hm = max(s[0] for s in image_sizes)
+        return [2.0 ** round(math.log2(float(fh) / float(hm))) for fh, _ in feat_hws]
+
+    def forward(self, feats, boxes: Sequence[torch.Tensor], image_sizes) -> torch.Tensor:
+        """-> NHWC [sum k_i, P, P, C] (the reference's NCHW view is produced at the model boundary)."""
+        fl = [feats[k] for k in self.featmap_names]
+        dev = fl[0].device
+        rois = torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i), device=dev), b.to(torch.float32)], 1)
+                          for i, b in enumerate(boxes)], 0).contiguous()
+        scales = self.infer_scales([f.shape[1:3] for f in fl], image_sizes)
+        k_min = int(round(-math.log2(scales[0])))
+        return ops.roi_align(fl, rois, scales, self.output_size, self.sampling_ratio, k_min)
+
+
+# ------------------------------------------------------------------------------ box branch (a6)
+class TwoMLPHead(nn.Module):
+    def __init__(self, in_channels=256 * 7 * 7, representation_size=1024):
+        super().__init__()
+        self.fc6 = nn.Linear(in_channels, representation_size)
+        self.fc7 = nn.Linear(representation_size, representation_size)
+        self._pk, self._pk_key = None, None
+
+    def packed(self):
+        key = _key(self.parameters())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                # fc6 over flatten(C,7,7) == a 7x7 valid conv over the NHWC ROI tile
+                w6 = self.fc6.weight.view(self.fc6.out_features, 256, 7, 7)
+                self._pk = (ops.pack_conv(w6, self.fc6.bias), ops.pack_conv(self.fc7.weight, self.fc7.bias))
+            self._pk_key = key
+        return self._pk
+
+    def forward(self, x):                        # NHWC [K,7,7,256] -> [K,1024]
+        fc6, fc7 = self.packed()
+        x = ops.conv2d(x, fc6, relu=True).view(x.shape[0], -1)
+        return ops.linear(x, fc7, relu=True)
+
+
+class FastRCNNPredictor(nn.Module):
+    def __init__(self, in_channels=1024, num_classes=91):
+        super().__init__()
+        self.cls_score = nn.Linear(in_channels, num_classes)
+        self.bbox_pred = nn.Linear(in_channels, num_classes * 4)
+        self.num_classes = num_classes
+        self._pk, self._pk_key = None, None
+
+    def forward(self, x):
+        key = _key(self.parameters())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                self._pk = ops.pack_conv(torch.cat([self.cls_score.weight, self.bbox_pred.weight], 0),
+                                         torch.cat([self.cls_score.bias, self.bbox_pred.bias], 0))
+            self._pk_key = key
+        o = ops.linear(x, self._pk)
+        return o[:, :self.num_classes], o[:, self.num_classes:]
+
+
+# ------------------------------------------------------------------------------ mask branch (a8)
+class MaskRCNNHeads(nn.Module):
+    def __init__(self, in_channels=256, layers=(256, 256, 256, 256)):
+        super().__init__()
+        c = in_channels
+        for i, l in enumerate(layers, 1):
+            setattr(self, f"mask_fcn{i}", nn.Conv2d(c, l, 3, padding=1))
+            setattr(self, f"relu{i}", nn.ReLU(inplace=True))
+            c = l
+        self.n = len(layers)
+        self._pk, self._pk_key = None, None
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        for i in range(self.n):              # torchvision >= 0.13: ``mask_head.{i}.0.weight``
+            for s in ("weight", "bias"):
+                old = f"{prefix}{i}.0.{s}"
+                if old in state_dict:
+                    state_dict[f"{prefix}mask_fcn{i + 1}.{s}"] = state_dict.pop(old)
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def forward(self, x):                        # NHWC [K,14,14,256]
+        key = _key(self.parameters())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                self._pk = [ops.pack_conv(getattr(self, f"mask_fcn{i}").weight, getattr(self, f"mask_fcn{i}").bias, pad=1)
+                            for i in range(1, self.n + 1)]
+            self._pk_key = key
+        for pc in self._pk:
+            x = ops.conv2d(x, pc, relu=True)
+        return x
+
+
+class MaskRCNNPredictor(nn.Module):
+    def __init__(self, in_channels=256, dim_reduced=256, num_classes=91):
+        super().__init__()
+        self.conv5_mask = nn.ConvTranspose2d(in_channels, dim_reduced, 2, 2, 0)
+        self.relu = nn.ReLU(inplace=True)
+        self.mask_fcn_logits = nn.Conv2d(dim_reduced, num_classes, 1, 1, 0)
+        self.num_classes = num_classes
+        self._pk, self._pk_key = None, None
+
+    def forward(self, x):
+        """NHWC [K,14,14,256] -> logits [K,14,14,4*ncls]: the 2x2/s2 transposed conv is a 1x1 conv to
+        4 sub-pixel channel groups (a,b); the 1x1 logits conv commutes with the depth-to-space, so
+        it runs per group and ``seam_mask_select_f32`` reads the 28x28 map straight out of it."""
+        key = _key(self.parameters())
+        if self._pk is None or key != self._pk_key:
+            with torch.no_grad():
+                self._pk = (ops.pack_conv(self.conv5_mask.weight, self.conv5_mask.bias, transposed2x2=True),
+                            ops.pack_conv(self.mask_fcn_logits.weight, self.mask_fcn_logits.bias))
+            self._pk_key = key
+        up, logits = self._pk
+        k = x.shape[0]
+        y = ops.conv2d(x, up, relu=True)                                  # [K,14,14,4*256]
+        o = ops.linear(y.view(k * 14 * 14 * 4, -1), logits)              # [K*196*4, ncls]
+        return o.view(k, 14, 14, 4 * self.num_classes)
+
+
+def maskrcnn_inference(mask_logits_sub, labels: Sequence[torch.Tensor], num_classes: int):
+    """sigmoid + per-ROI label channel -> list of [k_i,1,28,28]."""
+    counts = [int(l.numel()) for l in labels]
+    prob = ops.mask_select(mask_logits_sub, torch.cat(list(labels)).to(torch.int64).contiguous(), num_classes)
+    return list(prob.split(counts, 0))
+
+
+def paste_masks_in_image(masks: torch.Tensor, boxes: torch.Tensor, img_hw, padding: int = 1) -> torch.Tensor:
+    """transform.postprocess mask paste [TV] -> [K,1,H,W].  The output is read by no caller of the
+    reference (stuffs/engine.py:15,118; evaluate_movingfashion.py never touches ``masks``); it is
+    produced for output-dict parity with device tensor ops (not a HIP kernel; outside the timed path)."""
+    import torch.nn.functional as F
+    m = masks.shape[-1]
+    scale = float(m + 2 * padding) / m
+    pm = F.pad(masks, (padding,) * 4)
+    wh = (boxes[:, 2] - boxes[:, 0]) * 0.5 * scale
+    hh = (boxes[:, 3] - boxes[:, 1]) * 0.5 * scale
+    xc = (boxes[:, 2] + boxes[:, 0]) * 0.5
+    yc = (boxes[:, 3] + boxes[:, 1]) * 0.5
+    eb = torch.stack((xc - wh, yc - hh, xc + wh, yc + hh), 1).to(torch.int64).cpu().tolist()
+    im_h, im_w = img_hw
+    out = masks.new_zeros((masks.shape[0], 1, im_h, im_w))
+    for i, b in enumerate(eb):
+        w, h = max(b[2] - b[0] + 1, 1), max(b[3] - b[1] + 1, 1)
+        r = F.interpolate(pm[i][None], size=(h, w), mode="bilinear", align_corners=False)[0, 0]
+        x0, x1 = max(b[0], 0), min(b[2] + 1, im_w)
+        y0, y1 = max(b[1], 0), min(b[3] + 1, im_h)
+        if x1 > x0 and y1 > y0:
+            out[i, 0, y0:y1, x0:x1] = r[(y0 - b[1]):(y1 - b[1]), (x0 - b[0]):(x1 - b[0])]
+    return out

@@ -1,0 +1,174 @@
+"""SEAM match heads, mirror of reference ``models/match_head.py`` (heads only).
+
+``MatchPredictor.forward(x, types) -> (x3, x5)``                      ref :66-76
+``TemporalAggregationNLB.forward(x, types, ids, x3_1_seq=None, x3_1_mask=None, x3_2=None,
+                                 getatt=False) -> 6- or 7-tuple``       ref :90-169
+
+Same constructor arguments, attribute names (``conv_seq, pool, linear, last,
+attention_scorer, newnlb, nlb, n_frames``) and state-dict keys as the reference, so
+checkpoints and callers (``stuffs/engine.py:158``, ``evaluate_movingfashion.py:42,73,258``,
+the aggregation losses at ``models/match_head.py:339``) are interchangeable.  The training
+losses of the reference file are callers of these heads, not part of the forward hot path.
+
+Arithmetic: trunk = 4 valid 3x3 implicit-GEMM convs + avg-pool + Linear/BatchNorm epilogue
+(``seam_conv2d_f32``), sequences -> one batched NLB+attention-pool launch
+(``seam_nlb_attnpool_f32``), pairwise classifier (``seam_pair_logits_f32``).  No CPU or
+eager fallback: CPU tensors / autograd raise.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+from .nlb import NONLocalBlock1D
+
+
+def _no_grad_guard(module: nn.Module, *tensors):
+    if torch.is_grad_enabled() and (module.training or any(t is not None and t.requires_grad for t in tensors)):
+        if any(p.requires_grad for p in module.parameters()) or any(
+                t is not None and t.requires_grad for t in tensors):
+            raise NotImplementedError(
+                "the HIP path is forward/inference only: call under torch.no_grad() with the module in "
+                "eval() (backward kernels + BatchNorm1d train mode are SURVEY.md 8f row f2, not built)")
+
+
+def pack_nlb_from_state(sd: dict, prefix: str = "") -> ops.PackedNLB:
+    """Build the NLB/attention kernel's weight pack from a flat (device) state dict."""
+    g = lambda k: sd[prefix + k]  # noqa: E731
+    return ops.PackedNLB(
+        w_proj_t=torch.cat([g("newnlb.theta.weight")[:, :, 0], g("newnlb.phi.weight")[:, :, 0],
+                            g("newnlb.g.weight")[:, :, 0]], 0).t().contiguous(),
+        b_proj=torch.cat([g("newnlb.theta.bias"), g("newnlb.phi.bias"), g("newnlb.g.bias")]).contiguous(),
+        w_cat=g("newnlb.concat_project.0.weight").reshape(256).contiguous(),
+        w_out_t=g("newnlb.W.weight")[:, :, 0].t().contiguous(),
+        b_out=g("newnlb.W.bias").contiguous(),
+        w_att=g("attention_scorer.weight").reshape(256).contiguous(),
+        b_att=g("attention_scorer.bias").reshape(1).contiguous())
+
+
+class MatchPredictor(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv_seq = nn.Sequential(nn.Conv2d(256, 256, 3), nn.ReLU(),
+                                      nn.Conv2d(256, 256, 3), nn.ReLU(),
+                                      nn.Conv2d(256, 256, 3), nn.ReLU(),
+                                      nn.Conv2d(256, 1024, 3), nn.ReLU())
+        self.pool = nn.Sequential(nn.AvgPool2d((6, 6)), nn.ReLU())
+        self.linear = nn.Sequential(nn.Linear(1024, 256), nn.BatchNorm1d(256))
+        self.last = nn.Linear(256, 2)
+        self._trunk_pk = None
+        self._trunk_key = None
+
+    # ---- trunk: conv_seq -> pool -> linear(+BN) ---------------------------------------------------
+    def _packed_trunk(self):
+        bn = self.linear[1]
+        ps = [self.conv_seq[i].weight for i in (0, 2, 4, 6)] + [self.conv_seq[i].bias for i in (0, 2, 4, 6)] + [
+            self.linear[0].weight, self.linear[0].bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._trunk_pk is None or key != self._trunk_key:
+            with torch.no_grad():
+                convs = [ops.pack_conv(self.conv_seq[i].weight, self.conv_seq[i].bias) for i in (0, 2, 4, 6)]
+                lin = ops.pack_conv(self.linear[0].weight, self.linear[0].bias,
+                                    (bn.weight, bn.bias, bn.running_mean, bn.running_var), bn_eps=bn.eps)
+            self._trunk_pk, self._trunk_key = (convs, lin), key
+        return self._trunk_pk
+
+    def trunk_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        """x NHWC [K,14,14,256] -> x3 [K,256]   (ref :67-69 / :93-95)."""
+        if x.shape[0] == 0:
+            return torch.empty((0, 256), dtype=torch.float32, device=x.device)
+        convs, lin = self._packed_trunk()
+        for pc in convs:                       # 14 -> 12 -> 10 -> 8 -> 6, ReLU fused
+            x = ops.conv2d(x, pc, relu=True)
+        x = ops.avgpool(x)                     # AvgPool2d(6,6); the following ReLU is a no-op (x >= 0)
+        return ops.linear(x, lin)              # Linear + BatchNorm1d(eval) folded into the epilogue
+
+    def trunk(self, x: torch.Tensor) -> torch.Tensor:
+        """x NCHW [K,256,14,14] (the reference's layout) -> x3 [K,256]."""
+        if self.linear[1].training and torch.is_grad_enabled():
+            raise NotImplementedError("BatchNorm1d train mode / autograd is not built (SURVEY.md 8f row f2)")
+        return self.trunk_nhwc(ops.nchw_to_nhwc(x.detach()))
+
+    def pair(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """x5 = last((a_i - b_j)^2): [Q,256] x [G,256] -> [Q,G,2]   (ref :73-74, :161-162)."""
+        return ops.pair_logits(a, b, self.last.weight, self.last.bias)
+
+    def forward(self, x, types):
+        _no_grad_guard(self, x)
+        x3 = self.trunk(x)
+        types = torch.as_tensor(types).to(x3.device)       # callers pass a CPU IntTensor (video_matchrcnn.py:307)
+        x5 = self.pair(x3[types == 0], x3[types == 1])
+        return x3, x5
+
+
+class TemporalAggregationNLB(MatchPredictor):
+    def __init__(self, d_model=256):
+        super().__init__()
+        # same parameters and same forward as MatchPredictor, plus temporal aggregation (ref :81-88)
+        self.n_frames = -1
+        self.attention_scorer = nn.Linear(d_model, 1)
+        self.newnlb = NONLocalBlock1D(in_channels=d_model, sub_sample=False, bn_layer=False)
+        self.nlb = True
+
+    # ---- sequence aggregation: NLB (len > 1) + softmax attention pooling ---------------------------
+    def aggregate(self, seq_tm: torch.Tensor, lens: torch.Tensor, want_att: bool = False):
+        """seq_tm: time-major [T,S,256] (rows >= len[s] ignored); lens int32 [S] on device."""
+        t, s = seq_tm.shape[0], seq_tm.shape[1]
+        pk = self.newnlb.packed(self.attention_scorer)
+        return ops.nlb_attnpool(seq_tm, s * 256, 256, lens, s, t, pk, use_nlb=1 if self.nlb else 0,
+                                want_att=want_att)
+
+    def forward(self, x, types, ids, x3_1_seq=None, x3_1_mask=None, x3_2=None, getatt=False):
+        _no_grad_guard(self, x, x3_1_seq, x3_2)
+        attention_scores = None
+        if x3_1_seq is None:
+            # ---------------- Mode A: raw ROI features (ref :92-132) ----------------
+            x3 = self.trunk(x)
+            dev = x3.device
+            types_c = torch.as_tensor(types).cpu()
+            ids_c = torch.as_tensor(ids).cpu()
+            sel0 = (types_c == 0).nonzero().view(-1)
+            x3_1_ids_c = ids_c[sel0]
+            x3_2 = x3[(types_c == 1).to(dev)]
+            if x3_1_ids_c.numel() > 0:
+                # packing rules: sequences ordered by sorted unique id; maxlen = modal count;
+                # dummy zero row 0; mask True on padding (ref :98-111)
+                uniq, inv, counts = torch.unique(x3_1_ids_c, sorted=True, return_inverse=True, return_counts=True)
+                n_seqs, maxlen = int(uniq.numel()), int(counts.max())
+                order = torch.argsort(inv, stable=True)                 # rows grouped by sequence, original order kept
+                starts = torch.cumsum(counts, 0) - counts
+                pos = torch.arange(order.numel()) - starts[inv[order]]    # position inside its sequence
+                x3_1_seq = torch.zeros((1 + maxlen, n_seqs, 256), device=dev, dtype=x3.dtype)
+                rows = x3[sel0[order].to(dev)]
+                x3_1_seq[(pos + 1).to(dev), inv[order].to(dev)] = rows
+                x3_1_mask = (torch.arange(1 + maxlen)[None, :] > counts[:, None]).to(dev)
+                lens = counts.to(torch.int32).to(dev)
+                x3_1b, att = self.aggregate(x3_1_seq[1:], lens, getatt)
+                if getatt:
+                    attention_scores = [att[i, :int(c)].reshape(-1, 1) for i, c in enumerate(counts)]
+            else:
+                x3_1b = None
+            x3_1_ids = x3_1_ids_c.to(torch.as_tensor(ids).device) if isinstance(ids, torch.Tensor) else x3_1_ids_c
+        else:
+            # ---------------- Mode B: pre-extracted descriptors (ref :133-158) ----------------
+            dev = x3_1_seq.device
+            tp1, n_seqs = x3_1_seq.shape[0], x3_1_seq.shape[1]
+            m = x3_1_mask.to(dev)
+            first = torch.where(m.any(1), m.to(torch.int32).argmax(1), torch.full((n_seqs,), tp1, device=dev))
+            lens = (first - 1).clamp(min=0).to(torch.int32)             # slice 1:first_masked (ref :136-139)
+            seq = x3_1_seq.detach().to(torch.float32).contiguous()
+            x3_1b, att = self.aggregate(seq[1:], lens, getatt)
+            if getatt:
+                lc = lens.cpu().tolist()
+                attention_scores = [att[i, :n].reshape(-1, 1) for i, n in enumerate(lc)]
+            x3_2 = x3_2.detach().to(torch.float32)
+            x3_1_ids = torch.zeros((1, 2))      # just to have numel > 0 (ref :158)
+
+        x5 = self.pair(x3_1b, x3_2) if x3_1b is not None else None
+        if getatt:
+            return x3_1b, x3_2, x5, x3_1_seq, x3_1_mask, x3_1_ids, attention_scores
+        return x3_1b, x3_2, x5, x3_1_seq, x3_1_mask, x3_1_ids
+
+
+TemporalAggregation = TemporalAggregationNLB

@@ -1,0 +1,222 @@
+"""SEAM video model, mirror of reference ``models/video_matchrcnn.py``.
+
+``videomatchrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91,
+pretrained_backbone=True, n_frames=3, **kwargs)``                      ref :331-343
+``VideoMatchRCNN.forward(images, targets=None)`` -> eval: list of dicts with keys
+``boxes, labels, scores, masks, match_features, w, b, roi_features``     ref :239-253,293,310-314
+``VideoMatchRCNN.load_saved_matchrcnn(sd)``                              ref :325-328
+``model.roi_heads.{match_predictor, temporal_aggregator}``               ref :33-36
+
+The reference subclasses torchvision's ``MaskRCNN``; here the same module tree (same
+state-dict keys) is assembled from ``models/detection.py`` and every stage launches the
+gfx950 kernels.  Inference only: ``forward`` in training mode raises (the reference's own
+training loop runs this model under ``eval()`` + ``no_grad``, stuffs/engine.py:113-116).
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F   # softmax of 14 class logits in postprocess_detections only
+from torch import nn
+
+from .. import ops
+from . import detection as det
+from .match_head import MatchPredictor, TemporalAggregationNLB as TemporalAggregation
+
+model_urls = {
+    'maskrcnn_resnet50_fpn_coco':
+        'https://download.pytorch.org/models/maskrcnn_resnet50_fpn_coco-bf2d0c1e.pth',
+}
+
+
+class TemporalRoIHeads(nn.Module):
+    """Eval branch of the reference's ``TemporalRoIHeads`` (ref :19-316).  ``features`` are the
+    library's NHWC FPN maps; everything else keeps the reference's meaning."""
+
+    video = True                    # emit 'roi_features' (ref :314); NewRoIHeads does not
+    fallback_score = 0.1            # ref :252 (1.0 in models/matchrcnn.py:377)
+
+    def __init__(self, num_classes=91, n_frames=3, box_score_thresh=0.05, box_nms_thresh=0.5,
+                 box_detections_per_img=100):
+        super().__init__()
+        self.n_frames = n_frames
+        self.box_roi_pool = det.MultiScaleRoIAlign(("0", "1", "2", "3"), 7, 2)
+        self.box_head = det.TwoMLPHead(256 * 7 * 7, 1024)
+        self.box_predictor = det.FastRCNNPredictor(1024, num_classes)
+        self.mask_roi_pool = det.MultiScaleRoIAlign(("0", "1", "2", "3"), 14, 2)
+        self.mask_head = det.MaskRCNNHeads(256, (256, 256, 256, 256))
+        self.mask_predictor = det.MaskRCNNPredictor(256, 256, num_classes)
+        self.match_predictor = MatchPredictor()
+        self.temporal_aggregator = TemporalAggregation()
+        self.keypoint_roi_pool = self.keypoint_head = self.keypoint_predictor = None
+        self.score_thresh = box_score_thresh
+        self.nms_thresh = box_nms_thresh
+        self.detections_per_img = box_detections_per_img
+        self.num_classes = num_classes
+        self.with_masks = True      # set False to skip the (caller-unused) mask branch
+
+    has_mask = property(lambda self: self.mask_roi_pool is not None and self.mask_head is not None
+                        and self.mask_predictor is not None)
+    has_keypoint = property(lambda self: False)
+    has_match = property(lambda self: self.match_predictor is not None)
+
+    # ref :154-205 -- softmax, decode (weights 10,10,5,5), clip, drop background, score > thr,
+    # remove small, per-class NMS, top-k.  Decode/clip and the NMS bit-matrix + scan are HIP kernels.
+    def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes):
+        num_classes = class_logits.shape[-1]
+        counts = [len(p) for p in proposals]
+        pred_scores = F.softmax(class_logits, -1).split(counts, 0)
+        regs = box_regression.split(counts, 0)
+        all_boxes, all_scores, all_labels = [], [], []
+        for reg, scores, props, shape in zip(regs, pred_scores, proposals, image_shapes):
+            dev = scores.device
+            boxes = ops.decode_boxes(reg.contiguous(), props.contiguous(), (10.0, 10.0, 5.0, 5.0), shape)
+            boxes = boxes.view(-1, num_classes, 4)
+            labels = torch.arange(num_classes, device=dev).view(1, -1).expand_as(scores)
+            boxes, scores, labels = boxes[:, 1:].reshape(-1, 4), scores[:, 1:].flatten(), labels[:, 1:].flatten()
+            inds = torch.nonzero(scores > self.score_thresh).squeeze(1)
+            boxes, scores, labels = boxes[inds], scores[inds], labels[inds]
+            keep = ((boxes[:, 2] - boxes[:, 0]) >= 1e-2) & ((boxes[:, 3] - boxes[:, 1]) >= 1e-2)
+            boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+            keep = det.batched_nms(boxes, scores, labels, self.nms_thresh)[:self.detections_per_img]
+            all_boxes.append(boxes[keep])
+            all_scores.append(scores[keep])
+            all_labels.append(labels[keep])
+        return all_boxes, all_scores, all_labels
+
+    def detect(self, features, proposals, image_shapes):
+        """box branch (ref :225-253)."""
+        box_features = self.box_roi_pool(features, proposals, image_shapes)
+        box_features = self.box_head(box_features)
+        class_logits, box_regression = self.box_predictor(box_features)
+        boxes, scores, labels = self.postprocess_detections(class_logits, box_regression, proposals, image_shapes)
+        result = []
+        for i in range(len(boxes)):
+            if boxes[i].numel() > 0:
+                result.append(dict(boxes=boxes[i], labels=labels[i], scores=scores[i]))
+            else:   # empty image -> full-image fallback detection (ref :246-253)
+                dev = boxes[i].device
+                result.append(dict(
+                    boxes=torch.tensor([[0.0, 0.0, float(image_shapes[i][1]), float(image_shapes[i][0])]], device=dev),
+                    labels=torch.tensor([0], device=dev),
+                    scores=torch.tensor([self.fallback_score], device=dev)))
+        return result
+
+    def match_branch(self, features, result, image_shapes, targets=None):
+        """mask + match branches on the detections (ref :255-314)."""
+        if targets is not None:     # eval with ground truth: prepend GT boxes, score 1 (ref :256-262)
+            assert len(targets) == len(result)
+            for t, r in zip(targets, result):
+                dev = r["boxes"].device
+                r["boxes"] = torch.cat([t["boxes"].to(dev), r["boxes"]])
+                r["labels"] = torch.cat([t["labels"].to(dev), r["labels"]])
+                r["scores"] = torch.cat([torch.ones((t["labels"].numel(),), device=dev), r["scores"]])
+        mask_proposals = [r["boxes"] for r in result]
+        roi_nhwc = self.mask_roi_pool(features, mask_proposals, image_shapes)      # [K,14,14,256]
+        counts = [len(p) for p in mask_proposals]
+        if self.has_mask and self.with_masks:
+            logits = self.mask_predictor(self.mask_head(roi_nhwc))
+            probs = det.maskrcnn_inference(logits, [r["labels"] for r in result], self.num_classes)
+            for pr, r in zip(probs, result):
+                r["masks"] = pr
+        if self.has_match and roi_nhwc.shape[0] > 0:
+            # types = 0 for image 0's ROIs, 1 for all others (ref :299-307); the pairwise logits the
+            # reference computes here are dropped by every caller (ref :309), only x3 is kept
+            final_features = self.match_predictor.trunk_nhwc(roi_nhwc)
+            roi_nchw = ops.nhwc_to_nchw(roi_nhwc) if self.video else None
+            off = 0
+            for r, c in zip(result, counts):
+                r['match_features'] = final_features[off:off + c]
+                r['w'] = self.match_predictor.last.weight
+                r['b'] = self.match_predictor.last.bias
+                if self.video:
+                    r['roi_features'] = roi_nchw[off:off + c]
+                off += c
+        return result
+
+    def forward(self, features, proposals, image_shapes, targets=None):
+        if targets is not None:
+            for t in targets:
+                assert t["boxes"].dtype.is_floating_point, 'target boxes must of float type'
+                assert t["labels"].dtype == torch.int64, 'target labels must of int64 type'
+        if self.training:
+            raise NotImplementedError("training branch (losses, proposal sampling) is outside the forward hot path")
+        result = self.detect(features, proposals, image_shapes)
+        return self.match_branch(features, result, image_shapes, targets), {}
+
+
+class VideoMatchRCNN(nn.Module):
+    roi_heads_cls = TemporalRoIHeads
+
+    def __init__(self, backbone, num_classes, n_frames=3, min_size=800, max_size=1333,
+                 rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000, rpn_nms_thresh=0.7,
+                 box_score_thresh=0.05, box_nms_thresh=0.5, box_detections_per_img=100, **kwargs):
+        super().__init__()
+        self.transform = det.GeneralizedRCNNTransform(min_size, max_size)
+        self.backbone = backbone
+        self.rpn = det.RegionProposalNetwork(rpn_pre_nms_top_n_test, rpn_post_nms_top_n_test, rpn_nms_thresh)
+        self.roi_heads = self.roi_heads_cls(num_classes, n_frames, box_score_thresh, box_nms_thresh,
+                                            box_detections_per_img)
+        self._ignored_kwargs = kwargs       # training-only knobs of torchvision's MaskRCNN ctor
+
+    def load_saved_matchrcnn(self, sd):
+        """phase-1 -> phase-2 hand-off (ref :325-328)."""
+        self.load_state_dict(sd, strict=False)
+        self.roi_heads.temporal_aggregator.load_state_dict(
+            deepcopy(self.roi_heads.match_predictor.state_dict()), strict=False)
+
+    # ---- stages ------------------------------------------------------------------------------------
+    def extract_features(self, images: Sequence[torch.Tensor]):
+        x, sizes, orig = self.transform(images)
+        return self.backbone(x), sizes, orig, (x.shape[1], x.shape[2])
+
+    def postprocess(self, result, sizes, orig):
+        for r, sz, o in zip(result, sizes, orig):
+            boxes = det.GeneralizedRCNNTransform.rescale_boxes(r["boxes"], sz, o)
+            r["boxes"] = boxes
+            if "masks" in r:
+                r["masks"] = det.paste_masks_in_image(r["masks"], boxes, o)
+        return result
+
+    def forward(self, images, targets=None):
+        if self.training:
+            raise NotImplementedError(
+                "VideoMatchRCNN on HIP is the inference forward; the reference's training loop calls it under "
+                "model.eval() + torch.no_grad() (stuffs/engine.py:113-116)")
+        images = list(images)
+        if not images:
+            return []
+        feats, sizes, orig, padded = self.extract_features([i.detach() for i in images])
+        proposals = self.rpn(feats, sizes, padded)
+        if targets is not None:        # GT boxes arrive in original-image pixels -> resized frame
+            targets = [dict(t, boxes=det.GeneralizedRCNNTransform.rescale_boxes(
+                t["boxes"].to(feats["0"].device).to(torch.float32), o, s)) for t, s, o in zip(targets, sizes, orig)]
+        result, _ = self.roi_heads(feats, proposals, sizes, targets)
+        return self.postprocess(result, sizes, orig)
+
+    @torch.no_grad()
+    def forward_fixed_rois(self, images, rois: Sequence[torch.Tensor], run_rpn_head: bool = True):
+        """Extension used by the BASELINE.json "fixed ROI" configs: the given boxes (resized-image
+        pixels, one [k_i,4] tensor per image) replace RPN proposals + box head + NMS; everything
+        downstream (RoIAlign 14x14, mask head, match trunk) is the regular forward."""
+        feats, sizes, orig, padded = self.extract_features(list(images))
+        rpn_out = self.rpn.head(list(feats.values())) if run_rpn_head else None
+        dev = feats["0"].device
+        result = [dict(boxes=b.to(dev).to(torch.float32), labels=torch.ones(len(b), dtype=torch.int64, device=dev),
+                       scores=torch.ones(len(b), device=dev)) for b in rois]
+        result = self.roi_heads.match_branch(feats, result, sizes)
+        return result, feats, rpn_out
+
+
+def videomatchrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pretrained_backbone=True,
+                                n_frames=3, **kwargs):
+    if pretrained:
+        pretrained_backbone = False
+    backbone = det.resnet_fpn_backbone('resnet50', pretrained_backbone)
+    model = VideoMatchRCNN(backbone, num_classes, n_frames, **kwargs)
+    if pretrained:
+        raise RuntimeError("pretrained=True needs a download (" + model_urls['maskrcnn_resnet50_fpn_coco'] +
+                           "); fetch it yourself and call model.load_state_dict(state_dict)")
+    return model

@@ -1,0 +1,297 @@
+"""Launch wrappers over the C ABI (``include/seam_hip.h``): torch tensors in, torch tensors out.
+
+torch is plumbing only here -- device memory (``torch.empty``), the current HIP stream
+and raw ``data_ptr()`` values handed to ``libseam_hip.so``.  Every op requires CUDA(HIP)
+fp32 contiguous tensors and raises otherwise: there is no CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _native
+
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype=F32, name: str = "tensor") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _native.SeamNativeError(f"{name}: expected a tensor on the HIP device (no CPU path exists)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------ conv
+@dataclass
+class PackedConv:
+    """Weights of one conv/linear in the kernel's layout + its fused epilogue vectors."""
+    w: torch.Tensor                 # [rows_padded, kred]
+    scale: Optional[torch.Tensor]   # [K] or None
+    shift: Optional[torch.Tensor]   # [K] or None
+    K: int
+    Cstore: int
+    R: int
+    S: int
+    stride: int = 1
+    pad: int = 0
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None, *, stride: int = 1,
+              pad: int = 0, cstore: Optional[int] = None, transposed2x2: bool = False,
+              bn_eps: float = 1e-5) -> PackedConv:
+    """Pack a PyTorch-layout weight for ``conv2d``.
+
+    weight: Conv2d [K,Cin,R,S] | Linear [K,Cin] | (transposed2x2) ConvTranspose2d [Cin,Cout,2,2]
+    bn:     optional (weight, bias, running_mean, running_var) folded into the epilogue:
+            FrozenBatchNorm2d [TV] / BatchNorm1d eval (ref models/match_head.py:62)."""
+    lib = _native.lib()
+    weight = _req(weight.detach(), name="weight")
+    if transposed2x2:
+        cin, cout = weight.shape[0], weight.shape[1]
+        K, R, S, mode = 4 * cout, 1, 1, 1
+    else:
+        if weight.dim() == 2:
+            weight = weight[:, :, None, None]
+        if weight.dim() == 3:
+            weight = weight[:, :, :, None]
+        weight = weight.contiguous()
+        K, cin, R, S = weight.shape
+        mode = 0
+    cs = cstore if cstore is not None else ((cin + 3) // 4) * 4
+    rows = lib.seam_conv_rows_padded(K)
+    kred = lib.seam_conv_kred(cs, R, S)
+    wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
+    _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
+                  "seam_pack_conv_weight_f32")
+    scale = shift = None
+    if bias is not None:
+        bias = bias.detach().to(F32)
+        if transposed2x2:
+            bias = bias.repeat(4)
+    if bn is not None:
+        bw, bb, rm, rv = (t.detach().to(F32) for t in bn)
+        scale = (bw * torch.rsqrt(rv + bn_eps)).contiguous()
+        shift = bb - rm * scale
+        if bias is not None:
+            shift = shift + bias * scale
+        shift = shift.contiguous()
+    elif bias is not None:
+        shift = bias.contiguous()
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad)
+
+
+def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC implicit-GEMM conv (+scale/shift, +residual, +ReLU) -> NHWC [N,Ho,Wo,K]."""
+    x = _req(x, name="x")
+    n, h, w, c = x.shape
+    if c != pc.Cstore:
+        raise ValueError(f"conv2d: input has {c} channels, weights packed for {pc.Cstore}")
+    ho = (h + 2 * pc.pad - pc.R) // pc.stride + 1
+    wo = (w + 2 * pc.pad - pc.S) // pc.stride + 1
+    y = out if out is not None else torch.empty((n, ho, wo, pc.K), dtype=F32, device=x.device)
+    if residual is not None:
+        residual = _req(residual, name="residual")
+        if residual.shape != y.shape:
+            raise ValueError("conv2d: residual shape mismatch")
+    _native.check(_native.lib().seam_conv2d_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual),
+                                                _ptr(y), n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad,
+                                                1 if relu else 0, _stream()), "seam_conv2d_f32")
+    return y
+
+
+def linear(x: torch.Tensor, pc: PackedConv, relu: bool = False) -> torch.Tensor:
+    """[M,C] x packed [K,C] -> [M,K] through the conv kernel (1x1 on a 1x1 map)."""
+    m, c = x.shape
+    return conv2d(x.view(m, 1, 1, c), pc, relu).view(m, pc.K)
+
+
+# ------------------------------------------------------------------------------ elementwise
+def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, wp: int) -> torch.Tensor:
+    """normalise + resize + pad + CHW->NHWC4 for a list of images -> [N,hp,wp,4]."""
+    lib = _native.lib()
+    out = torch.empty((len(images), hp, wp, 4), dtype=F32, device=images[0].device)
+    for i, (img, (oh, ow)) in enumerate(zip(images, sizes)):
+        img = _req(img, name="image")
+        if img.dim() != 3 or img.shape[0] != 3:
+            raise ValueError("images must be [3,H,W]")
+        _native.check(lib.seam_preprocess_f32(_ptr(img), C.c_void_p(out[i].data_ptr()), img.shape[1], img.shape[2],
+                                              oh, ow, hp, wp, _stream()), "seam_preprocess_f32")
+    return out
+
+
+def maxpool2d(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+    x = _req(x)
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty((n, ho, wo, c), dtype=F32, device=x.device)
+    _native.check(_native.lib().seam_maxpool2d_f32(_ptr(x), _ptr(y), n, h, w, c, k, stride, pad, _stream()),
+                  "seam_maxpool2d_f32")
+    return y
+
+
+def upsample_add_(lat: torch.Tensor, top: torch.Tensor) -> torch.Tensor:
+    lat, top = _req(lat), _req(top)
+    n, h, w, c = lat.shape
+    _native.check(_native.lib().seam_upsample_add_f32(_ptr(lat), _ptr(top), n, h, w, top.shape[1], top.shape[2], c,
+                                                      _stream()), "seam_upsample_add_f32")
+    return lat
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x)
+    b, c = x.shape[0], x.shape[1]
+    l = x[0, 0].numel()
+    y = torch.empty((b,) + tuple(x.shape[2:]) + (c,), dtype=F32, device=x.device)
+    if b:
+        _native.check(_native.lib().seam_nchw_to_nhwc_f32(_ptr(x), _ptr(y), b, c, l, _stream()), "seam_nchw_to_nhwc_f32")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x)
+    b, c = x.shape[0], x.shape[-1]
+    sp = tuple(x.shape[1:-1])
+    l = 1
+    for s in sp:
+        l *= s
+    y = torch.empty((b, c) + sp, dtype=F32, device=x.device)
+    if b:
+        _native.check(_native.lib().seam_nhwc_to_nchw_f32(_ptr(x), _ptr(y), b, l, c, _stream()), "seam_nhwc_to_nchw_f32")
+    return y
+
+
+def avgpool(x: torch.Tensor) -> torch.Tensor:
+    """NHWC [K,h,w,C] -> [K,C] mean over the spatial positions."""
+    x = _req(x)
+    k, c = x.shape[0], x.shape[-1]
+    l = x[0].numel() // c
+    y = torch.empty((k, c), dtype=F32, device=x.device)
+    if k:
+        _native.check(_native.lib().seam_avgpool_f32(_ptr(x), _ptr(y), k, l, c, _stream()), "seam_avgpool_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------ RoIAlign
+def roi_align(feats: Sequence[torch.Tensor], rois: torch.Tensor, scales: Sequence[float], pooled: int,
+              sampling_ratio: int = 2, k_min: int = 2, levels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """feats: 4 NHWC maps; rois [K,5] (batch_idx,x1,y1,x2,y2) -> NHWC [K,P,P,C]."""
+    feats = [_req(f) for f in feats]
+    rois = _req(rois, name="rois")
+    k = rois.shape[0]
+    c = feats[0].shape[-1]
+    out = torch.empty((k, pooled, pooled, c), dtype=F32, device=rois.device)
+    if k == 0:
+        return out
+    hw = (C.c_int * 8)(*[d for f in feats for d in (f.shape[1], f.shape[2])])
+    if levels is not None:
+        levels = _req(levels, torch.int32, "levels")
+    _native.check(_native.lib().seam_roi_align_f32(_ptr(feats[0]), _ptr(feats[1]), _ptr(feats[2]), _ptr(feats[3]), hw,
+                                                   c, scales[0], scales[1], scales[2], scales[3], k_min, _ptr(rois),
+                                                   _ptr(levels), _ptr(out), k, pooled, sampling_ratio, _stream()),
+                  "seam_roi_align_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------ SEAM heads
+@dataclass
+class PackedNLB:
+    w_proj_t: torch.Tensor   # [256,384]
+    b_proj: torch.Tensor     # [384]
+    w_cat: torch.Tensor      # [256]
+    w_out_t: torch.Tensor    # [128,256]
+    b_out: torch.Tensor      # [256]
+    w_att: torch.Tensor      # [256]
+    b_att: torch.Tensor      # [1]
+
+
+def nlb_attnpool(seq: torch.Tensor, t_stride: int, s_stride: int, lens: torch.Tensor, n_seq: int, t_max: int,
+                 pk: PackedNLB, use_nlb: bool = True, want_att: bool = False, want_z: bool = False):
+    """Batched non-local block + attention pooling.
+    Returns (out[S,256], att[S,Tmax] | None) and additionally z[S,Tmax,256] when want_z."""
+    lib = _native.lib()
+    seq = _req(seq, name="seq")
+    lens = _req(lens, torch.int32, "lens")
+    out = torch.empty((n_seq, 256), dtype=F32, device=seq.device)
+    att = torch.zeros((n_seq, t_max), dtype=F32, device=seq.device) if want_att else None
+    z = torch.zeros((n_seq, t_max, 256), dtype=F32, device=seq.device) if want_z else None
+    if n_seq == 0:
+        return (out, att, z) if want_z else (out, att)
+    ws = torch.empty((int(lib.seam_nlb_workspace_floats(n_seq, t_max)),), dtype=F32, device=seq.device)
+    _native.check(lib.seam_nlb_attnpool_f32(_ptr(seq), t_stride, s_stride, _ptr(lens), n_seq, t_max, _ptr(pk.w_proj_t),
+                                            _ptr(pk.b_proj), _ptr(pk.w_cat), _ptr(pk.w_out_t), _ptr(pk.b_out),
+                                            _ptr(pk.w_att), _ptr(pk.b_att), _ptr(out), _ptr(att), _ptr(z), _ptr(ws),
+                                            int(use_nlb), _stream()), "seam_nlb_attnpool_f32")
+    return (out, att, z) if want_z else (out, att)
+
+
+def pair_logits(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """a[Q,D], b[G,D], w[2,D], bias[2] -> [Q,G,2]."""
+    a, b, w, bias = _req(a), _req(b), _req(w.detach()), _req(bias.detach())
+    q, g, d = a.shape[0], b.shape[0], a.shape[1]
+    out = torch.empty((q, g, 2), dtype=F32, device=a.device)
+    _native.check(_native.lib().seam_pair_logits_f32(_ptr(a), _ptr(b), _ptr(w), _ptr(bias), _ptr(out), q, g, d,
+                                                     _stream()), "seam_pair_logits_f32")
+    return out
+
+
+def rank_topk(logits: torch.Tensor, k: int):
+    """logits[Q,G,2] -> (idx int64 [Q,k], score [Q,k]) by descending softmax(x)[...,1]."""
+    logits = _req(logits)
+    q, g = logits.shape[0], logits.shape[1]
+    k = min(k, g)
+    idx = torch.empty((q, k), dtype=torch.int64, device=logits.device)
+    sc = torch.empty((q, k), dtype=F32, device=logits.device)
+    _native.check(_native.lib().seam_rank_topk_f32(_ptr(logits), _ptr(idx), _ptr(sc), q, g, k, _stream()),
+                  "seam_rank_topk_f32")
+    return idx, sc
+
+
+# ------------------------------------------------------------------------------ detection
+def decode_boxes(deltas: torch.Tensor, boxes: torch.Tensor, weights, clip_hw=None) -> torch.Tensor:
+    """deltas [N,ncls*4], boxes [N,4] -> [N,ncls*4]; optional clip to (h,w)."""
+    deltas, boxes = _req(deltas), _req(boxes)
+    n = boxes.shape[0]
+    ncls = deltas.shape[1] // 4
+    out = torch.empty_like(deltas)
+    ch, cw = (float(clip_hw[0]), float(clip_hw[1])) if clip_hw is not None else (0.0, 0.0)
+    _native.check(_native.lib().seam_decode_boxes_f32(_ptr(deltas), _ptr(boxes), _ptr(out), n, ncls, *map(float, weights),
+                                                      ch, cw, _stream()), "seam_decode_boxes_f32")
+    return out
+
+
+def nms_sorted(boxes: torch.Tensor, thr: float) -> torch.Tensor:
+    """boxes [N,4] already sorted by descending score -> keep mask int32 [N]."""
+    boxes = _req(boxes)
+    n = boxes.shape[0]
+    keep = torch.empty((n,), dtype=torch.int32, device=boxes.device)
+    if n == 0:
+        return keep
+    nb = (n + 63) // 64
+    ws = torch.empty((n * nb,), dtype=torch.int64, device=boxes.device)
+    _native.check(_native.lib().seam_nms_sorted_f32(_ptr(boxes), _ptr(keep), n, float(thr), _ptr(ws), _stream()),
+                  "seam_nms_sorted_f32")
+    return keep
+
+
+def mask_select(logits: torch.Tensor, labels: torch.Tensor, ncls: int) -> torch.Tensor:
+    """logits [K,14,14,4*ncls] (sub-pixel groups) -> sigmoid prob of channel labels[k]: [K,1,28,28]."""
+    logits = _req(logits)
+    labels = _req(labels, torch.int64, "labels")
+    k = logits.shape[0]
+    out = torch.empty((k, 1, 28, 28), dtype=F32, device=logits.device)
+    _native.check(_native.lib().seam_mask_select_f32(_ptr(logits), _ptr(labels), _ptr(out), k, ncls, _stream()),
+                  "seam_mask_select_f32")
+    return out

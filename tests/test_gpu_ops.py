@@ -1,0 +1,259 @@
+"""GPU parity: every C-ABI kernel vs the CPU oracle on seeded inputs (run with -m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import seam_match_rcnn_amd.synth as synth
+from conftest import to_torch
+from oracle import detection as OD
+from oracle import heads as OH
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3          # north_star: 1e-3 relative fp32
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def assert_close(got, ref, rtol=RTOL, atol_scale=1e-4):
+    """allclose(rtol, atol = atol_scale * max|ref|): logits cross zero."""
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    atol = atol_scale * max(float(ref.abs().max()), 1e-30)
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bool(bad.any()), f"max err {float(err.max()):.3e} (tol {float(tol.min()):.3e}), {int(bad.sum())} bad of {bad.numel()}"
+
+
+def rnd(seed, shape, name="x"):
+    return torch.from_numpy(synth.normal(synth.stream_id(seed, name), shape))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import seam_match_rcnn_amd.ops as ops
+    return ops
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, stride, pad, bn, res, relu
+    (2, 64, 20, 24, 64, 1, 1, 0, True, False, True),
+    (1, 64, 30, 26, 256, 1, 1, 0, True, True, True),
+    (2, 128, 17, 19, 128, 3, 1, 1, True, False, True),
+    (2, 128, 18, 22, 128, 3, 2, 1, True, False, True),
+    (1, 256, 14, 14, 512, 1, 2, 0, True, False, False),
+    (1, 3, 64, 80, 64, 7, 2, 3, True, False, True),       # stem (3 -> 4 stored channels)
+    (3, 256, 14, 14, 256, 3, 1, 0, False, False, True),   # match trunk: valid 3x3
+    (2, 256, 8, 8, 1024, 3, 1, 0, False, False, True),
+    (1, 256, 13, 16, 15, 1, 1, 0, False, False, False),   # RPN logits+deltas fused (K=15)
+    (1, 256, 25, 32, 256, 3, 1, 1, False, False, False),  # FPN output conv (bias)
+    (2, 2048, 7, 9, 256, 1, 1, 0, False, False, False),   # FPN lateral C5
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(ops, case):
+    n, c, h, w, k, r, stride, pad, bn, res, relu = case
+    x = rnd(1, (n, c, h, w))
+    wt = rnd(2, (k, c, r, r), "w") * (1.0 / math.sqrt(c * r * r))
+    bias = None if bn else rnd(3, (k,), "b") * 0.1
+    bnp = None
+    ref = F.conv2d(x, wt, bias, stride, pad)
+    if bn:
+        bw = torch.from_numpy(synth.uniform(synth.stream_id(4, "bw"), (k,), 0.5, 1.5))
+        bb, rm = rnd(5, (k,), "bb") * 0.1, rnd(6, (k,), "rm") * 0.1
+        rv = torch.from_numpy(synth.uniform(synth.stream_id(7, "rv"), (k,), 0.5, 1.5))
+        bnp = (bw, bb, rm, rv)
+        sc = bw * (rv + 1e-5).rsqrt()
+        ref = ref * sc[None, :, None, None] + (bb - rm * sc)[None, :, None, None]
+    resid = None
+    if res:
+        resid = rnd(8, ref.shape, "res")
+        ref = ref + resid
+    if relu:
+        ref = F.relu(ref)
+    d = dev()
+    pc = ops.pack_conv(wt.to(d), None if bias is None else bias.to(d), None if bnp is None else tuple(t.to(d) for t in bnp),
+                       stride=stride, pad=pad)
+    xin = nhwc(x)
+    if c % 4:
+        xin = F.pad(xin, (0, 4 - c % 4))
+    y = ops.conv2d(xin.to(d), pc, relu, None if resid is None else nhwc(resid).to(d))
+    torch.cuda.synchronize()
+    assert_close(y.permute(0, 3, 1, 2), ref)
+
+
+def test_linear_and_fc6_as_conv(ops):
+    d = dev()
+    x = rnd(11, (37, 1024))
+    w, b = rnd(12, (256, 1024), "w") / 32.0, rnd(13, (256,), "b")
+    pc = ops.pack_conv(w.to(d), b.to(d))
+    assert_close(ops.linear(x.to(d), pc, relu=True), F.relu(F.linear(x, w, b)))
+    # fc6: flatten(C,7,7) @ W^T  ==  7x7 valid conv on the NHWC ROI tile
+    xr = rnd(14, (5, 256, 7, 7))
+    w6, b6 = rnd(15, (128, 256 * 49), "w6") / 112.0, rnd(16, (128,), "b6")
+    pc6 = ops.pack_conv(w6.view(128, 256, 7, 7).to(d), b6.to(d))
+    y = ops.conv2d(nhwc(xr).to(d), pc6, True).view(5, 128)
+    assert_close(y, F.relu(F.linear(xr.flatten(1), w6, b6)))
+
+
+def test_conv_transpose_2x2(ops):
+    d = dev()
+    x = rnd(17, (3, 256, 14, 14))
+    wt, b = rnd(18, (256, 64, 2, 2), "wt") / 16.0, rnd(19, (64,), "bt")
+    ref = F.relu(F.conv_transpose2d(x, wt, b, 2))                      # [3,64,28,28]
+    pc = ops.pack_conv(wt.to(d), b.to(d), transposed2x2=True)
+    y = ops.conv2d(nhwc(x).to(d), pc, True)                             # [3,14,14,4*64]
+    y = y.view(3, 14, 14, 2, 2, 64).permute(0, 5, 1, 3, 2, 4).reshape(3, 64, 28, 28)
+    assert_close(y, ref)
+
+
+@pytest.mark.parametrize("hw", [((64, 80), (64, 80)), ((60, 90), None), ((108, 192), None)])
+def test_preprocess(ops, hw):
+    (h, w), _ = hw
+    imgs = [torch.from_numpy(synth.uniform(synth.stream_id(20 + i, "img"), (3, h, w))) for i in range(2)]
+    ref, sizes = OD.transform(imgs, min_size=96, max_size=160)
+    # product side computes the same sizes on the host
+    from seam_match_rcnn_amd.models.detection import resized_size
+    psz = [resized_size(h, w, 96, 160)[:2] for _ in imgs]
+    assert [tuple(s) for s in sizes] == psz
+    hp, wp = ref.shape[-2:]
+    out = ops.preprocess([i.to(dev()) for i in imgs], psz, hp, wp)
+    assert_close(out[..., :3].permute(0, 3, 1, 2), ref, atol_scale=1e-5)
+    assert float(out[..., 3].abs().max()) == 0.0
+
+
+def test_maxpool_upsample_transpose_avgpool(ops):
+    d = dev()
+    x = rnd(30, (2, 64, 31, 37))
+    assert_close(ops.maxpool2d(nhwc(x).to(d), 3, 2, 1).permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2, 1), rtol=0, atol_scale=0)
+    assert_close(ops.maxpool2d(nhwc(x).to(d), 1, 2, 0).permute(0, 3, 1, 2), F.max_pool2d(x, 1, 2, 0), rtol=0, atol_scale=0)
+    lat, top = rnd(31, (2, 32, 26, 34)), rnd(32, (2, 32, 13, 17))
+    ref = lat + F.interpolate(top, size=lat.shape[-2:], mode="nearest")
+    got = ops.upsample_add_(nhwc(lat).to(d), nhwc(top).to(d))
+    assert_close(got.permute(0, 3, 1, 2), ref, rtol=1e-6)
+    r = rnd(33, (5, 256, 14, 14))
+    t = ops.nchw_to_nhwc(r.to(d))
+    assert torch.equal(t.cpu(), nhwc(r))
+    assert torch.equal(ops.nhwc_to_nchw(t).cpu(), r)
+    a = rnd(34, (7, 1024, 6, 6))
+    assert_close(ops.avgpool(nhwc(a).to(d)), F.avg_pool2d(a, 6).flatten(1), rtol=1e-5)
+
+
+def test_roi_align_multiscale(ops):
+    d = dev()
+    sizes = [(200, 200)] * 2
+    feats = [rnd(40 + i, (2, 256, 200 // 2 ** (i + 2) if i < 3 else 7, 200 // 2 ** (i + 2) if i < 3 else 7))
+             for i in range(4)]
+    feats = [rnd(40 + i, (2, 256, s, s)) for i, s in enumerate((50, 25, 13, 7))]
+    boxes = [torch.tensor([[10., 12., 60., 80.], [0., 0., 200., 200.], [150., 20., 199., 70.],
+                           [30.5, 40.25, 31.0, 40.5], [100., 100., 190., 195.], [-5., -8., 40., 30.]]),
+             torch.from_numpy(synth.fixed_rois(8, 200, 200))]
+    for pooled in (7, 14):
+        ref = OD.multiscale_roi_align(feats, boxes, sizes, pooled)
+        rois = torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i)), b], 1) for i, b in enumerate(boxes)])
+        scales = OD.infer_scales([f.shape[-2:] for f in feats], sizes)
+        out = ops.roi_align([nhwc(f).to(d) for f in feats], rois.to(d), scales, pooled)
+        assert_close(out.permute(0, 3, 1, 2), ref, atol_scale=1e-5)
+
+
+def test_nlb_attnpool_golden_and_oracle(ops, golden):
+    d = dev()
+    from seam_match_rcnn_amd.models.match_head import pack_nlb_from_state
+    p = to_torch(synth.temporal_aggregator_state(12))
+    pk = pack_nlb_from_state({k: v.to(d) for k, v in p.items()})
+    # golden Mode-B case: lens 10,1,4,7 ; time-major [11,4,256] with dummy row 0
+    seq = rnd(33, (11, 4, 256), "seq")
+    lens = golden["taB_lens"].tolist()
+    seq[0] = 0
+    for i, n in enumerate(lens):
+        seq[n + 1:, i] = 0
+    sd = seq.to(d)
+    out, att = ops.nlb_attnpool(sd[1:], 4 * 256, 256, torch.tensor(lens, dtype=torch.int32, device=d), 4, 10, pk,
+                                True, True)
+    assert_close(out, torch.from_numpy(golden["taB_x3_1b"]))
+    for i, n in enumerate(lens):
+        assert_close(att[i, :n], torch.from_numpy(golden[f"taB_att{i}"])[:, 0])
+    # long / ragged sequences vs the oracle (exercises the global-workspace path, T > 96)
+    lens2 = [130, 2, 97, 33, 0, 1]
+    tmax = max(lens2)
+    x = rnd(50, (len(lens2), tmax, 256), "long")
+    out2, att2 = ops.nlb_attnpool(x.to(d), 256, tmax * 256, torch.tensor(lens2, dtype=torch.int32, device=d),
+                                  len(lens2), tmax, pk, True, True)
+    for i, n in enumerate(lens2):
+        if n == 0:
+            assert float(out2[i].abs().max()) == 0.0
+            continue
+        ref, atts = OH.aggregate_sequences([x[i, :n]], p)
+        assert_close(out2[i], ref[0])
+        assert_close(att2[i, :n], atts[0][:, 0])
+
+
+@pytest.mark.parametrize("qg", [(3, 5), (32, 1000), (70, 333), (256, 5000)])
+def test_pair_logits_and_topk(ops, qg):
+    q, g = qg
+    d = dev()
+    a, b = rnd(60, (q, 256), "a"), rnd(61, (g, 256), "b")
+    w, bias = rnd(62, (2, 256), "w") / 16.0, rnd(63, (2,), "bias")
+    ref = OH.pair_logits(a, b, w, bias)
+    got = ops.pair_logits(a.to(d), b.to(d), w.to(d), bias.to(d))
+    assert_close(got, ref)
+    k = min(20, g)
+    idx, sc = ops.rank_topk(got, k)
+    ridx, rsc = OH.rank_topk(got.cpu(), k)          # same logits -> exact index parity (ties: lower index)
+    assert torch.equal(idx.cpu(), ridx)
+    assert_close(sc, rsc)
+
+
+def test_c2_golden_topk(ops, golden):
+    """BASELINE config 2 shapes (S=32,T=10,G=1000) against the reference-captured fixture."""
+    d = dev()
+    from seam_match_rcnn_amd.models.match_head import pack_nlb_from_state
+    p = to_torch(synth.temporal_aggregator_state(12))
+    pd = {k: v.to(d) for k, v in p.items()}
+    pk = pack_nlb_from_state(pd)
+    s, t, g = 32, 10, 1000
+    seq = torch.from_numpy(synth.normal(synth.stream_id(35, "seq_c2"), (t, s, 256))).to(d)
+    gal = torch.from_numpy(synth.gallery(36, g)).to(d)
+    out, _ = ops.nlb_attnpool(seq, s * 256, 256, torch.full((s,), t, dtype=torch.int32, device=d), s, t, pk)
+    assert_close(out, torch.from_numpy(golden["c2_x3_1b"]))
+    x5 = ops.pair_logits(out, gal, pd["last.weight"], pd["last.bias"])
+    assert_close(x5.reshape(-1)[::16], torch.from_numpy(golden["c2_x5_sample"]))
+    idx, sc = ops.rank_topk(x5, 20)
+    assert_close(sc, torch.from_numpy(golden["c2_top20_score"]))
+    for qi in range(s):
+        assert len(set(idx[qi].tolist()) ^ set(golden["c2_top20"][qi].tolist())) <= 2
+
+
+def test_decode_nms_maskselect(ops):
+    d = dev()
+    n = 700
+    ctr = torch.from_numpy(synth.uniform(synth.stream_id(70, "c"), (n, 2), 20, 380))
+    wh = torch.from_numpy(synth.uniform(synth.stream_id(71, "wh"), (n, 2), 8, 120))
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    deltas = rnd(72, (n, 8), "d") * 0.5
+    ref = OD.clip_boxes(OD.decode_boxes(deltas, boxes, (10., 10., 5., 5.)).view(n, 2, 4), (400, 416)).view(n, 8)
+    got = ops.decode_boxes(deltas.to(d), boxes.to(d), (10., 10., 5., 5.), (400, 416))
+    assert_close(got, ref, atol_scale=1e-6)
+    scores = torch.from_numpy(synth.uniform(synth.stream_id(73, "s"), (n,)))
+    order = torch.argsort(scores, descending=True, stable=True)
+    for thr in (0.3, 0.5, 0.7):
+        keep_ref = OD.nms(boxes, scores, thr)
+        keep = ops.nms_sorted(boxes[order].to(d), thr).cpu().bool()
+        assert torch.equal(order[keep], keep_ref)
+    logits = rnd(74, (6, 14, 28, 28), "ml")
+    labels = torch.tensor([1, 13, 0, 5, 5, 7])
+    ref = OD.maskrcnn_inference(logits, [labels])[0]
+    sub = logits.view(6, 14, 14, 2, 14, 2).permute(0, 2, 4, 3, 5, 1).reshape(6, 14, 14, 4 * 14).contiguous()
+    assert_close(ops.mask_select(sub.to(d), labels.to(d), 14), ref, rtol=1e-5)
