@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (soname libamdhip64.so.7).  It MUST be in the process before
+# libseam_hip.so is dlopen'ed, so that the library binds to the same runtime instance torch uses
+# (loading /opt/rocm's copy first gives two runtimes and "no ROCm-capable device" at launch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libseam_hip.so")
 

@@ -46,6 +46,12 @@ class PackedConv:
     S: int
     stride: int = 1
     pad: int = 0
+    Cin: int = 0                    # real (unpadded) input channels: algorithmic FLOP accounting
+
+
+# When set to a list, every conv launch is bracketed by HIP events on the launch stream and
+# (variant, algorithmic_flops, start_event, end_event) is appended (bench.py's roofline leg).
+CONV_TRACE = None
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None, *, stride: int = 1,
@@ -89,7 +95,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         shift = shift.contiguous()
     elif bias is not None:
         shift = bias.contiguous()
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad)
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin)
 
 
 def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Optional[torch.Tensor] = None,
@@ -106,9 +112,17 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         residual = _req(residual, name="residual")
         if residual.shape != y.shape:
             raise ValueError("conv2d: residual shape mismatch")
+    trace = CONV_TRACE
+    if trace is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _native.check(_native.lib().seam_conv2d_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual),
                                                 _ptr(y), n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad,
                                                 1 if relu else 0, _stream()), "seam_conv2d_f32")
+    if trace is not None:
+        e1.record()
+        variant = "conv_igemm_f32<128,128>" if pc.w.shape[0] % 128 == 0 else "conv_igemm_f32<128,64>"
+        trace.append((variant, 2.0 * n * ho * wo * pc.K * pc.R * pc.S * (pc.Cin or pc.Cstore), e0, e1))
     return y
 
 

@@ -1,0 +1,109 @@
+"""Data-parallel retrieval: clip sharding, RCCL all-gather of the product-descriptor bank,
+street-sequence vs. bank match + top-k  (BASELINE.json north_star).
+
+The reference has no counterpart for the collective (its "multi-GPU" is N independent
+processes, ref train_movingfashion.py:46-50; the gallery is a Python list concatenated with
+NumPy on rank 0, ref evaluate_movingfashion.py:45-47,82,92).  Here:
+
+  * clips are independent            -> rank r owns clips  r, r+W, r+2W, ...   (no collective)
+  * gallery products are independent -> rank r *computes* descriptors for products
+    [lo_r, hi_r) (each shop image goes through the extractor once, somewhere)
+  * the only exchange: every query sequence is matched against EVERY product, so the
+    descriptor shards are all-gathered into the full bank [G,256] on every rank -- one
+    ``all_gather_into_tensor`` (backend "nccl" == RCCL over xGMI), issued on a side stream so
+    it overlaps the street-side trunk / NLB work, then the local pairwise + top-k kernels run.
+
+Everything here works on CPU tensors with the gloo backend too (used by the world_size=2
+tests for the sharding / gather logic; the match itself always needs the HIP kernels).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo,hi) of n items for ``rank``; the first n % world ranks get one extra."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def clips_for_rank(n_clips: int, rank: int, world: int) -> List[int]:
+    """Round-robin clip ownership: r, r+W, r+2W, ..."""
+    return list(range(rank, n_clips, world))
+
+
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class BankGather:
+    """Handle of an in-flight all-gather of the product bank (``wait()`` -> [G,256])."""
+
+    def __init__(self, bank: torch.Tensor, g_total: int, work=None, stream=None, pad_rows: int = 0,
+                 sizes: Optional[List[int]] = None):
+        self.bank, self.g_total, self.work, self.stream = bank, g_total, work, stream
+        self.pad_rows, self.sizes = pad_rows, sizes
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.sizes is not None:      # ragged shards were padded to the largest: compact
+            m = max(self.sizes)
+            parts = [self.bank[i * m:i * m + s] for i, s in enumerate(self.sizes)]
+            return torch.cat(parts, 0)
+        return self.bank
+
+
+def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stream=None) -> BankGather:
+    """All-gather the per-rank descriptor shards ``local[g_r,256]`` (g_r from ``shard_range``)
+    into the full bank, product order preserved.  Asynchronous: returns a ``BankGather``.
+
+    side_stream: optional ``torch.cuda.Stream``; the collective is enqueued there (after the
+    producer of ``local`` on the current stream) so compute on the current stream overlaps it."""
+    world = _world(group)
+    if world == 1:
+        return BankGather(local, g_total)
+    rank = dist.get_rank(group)
+    sizes = [shard_range(g_total, r, world)[1] - shard_range(g_total, r, world)[0] for r in range(world)]
+    assert local.shape[0] == sizes[rank], (local.shape, sizes, rank)
+    m = max(sizes)
+    ragged = min(sizes) != m
+    src = local.contiguous()
+    if ragged:
+        pad = local.new_zeros((m, local.shape[1]))
+        pad[:src.shape[0]] = src
+        src = pad
+    bank = local.new_empty((world * m, local.shape[1]))
+    use_into = local.is_cuda or hasattr(dist, "all_gather_into_tensor")
+
+    def issue():
+        if use_into:
+            try:
+                return dist.all_gather_into_tensor(bank, src, group=group, async_op=True)
+            except (RuntimeError, NotImplementedError):
+                pass
+        return dist.all_gather(list(bank.view(world, m, -1).unbind(0)), src, group=group, async_op=True)
+
+    if local.is_cuda and side_stream is not None:
+        side_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side_stream):
+            work = issue()
+        return BankGather(bank, g_total, work, side_stream, sizes=sizes if ragged else None)
+    return BankGather(bank, g_total, issue(), None, sizes=sizes if ragged else None)
+
+
+@torch.no_grad()
+def match_sequences(aggregator, x3_1b: torch.Tensor, bank: torch.Tensor, k: int = 20):
+    """Aggregated street descriptors [S,256] vs the full bank [G,256] with the aggregator's
+    pairwise classifier (ref models/match_head.py:161-162), then score + rank
+    (ref evaluate_movingfashion.py:263-269).  -> (x5 [S,G,2], idx [S,k] int64, score [S,k])."""
+    from . import ops
+    x5 = aggregator.pair(x3_1b, bank)
+    idx, score = ops.rank_topk(x5, min(k, bank.shape[0]))
+    return x5, idx, score
