@@ -47,6 +47,27 @@ def pack_nlb_from_state(sd: dict, prefix: str = "") -> ops.PackedNLB:
         b_att=g("attention_scorer.bias").reshape(1).contiguous())
 
 
+def plan_sequences(types_c: torch.Tensor, ids_c: torch.Tensor):
+    """Host-side sequence packing plan of Mode A (ref models/match_head.py:96-111).
+
+    types_c / ids_c: CPU tensors [K].  Street rows (type 0) are grouped by *sorted unique id*;
+    ``maxlen`` = count of the modal id; inside a sequence rows keep their original order.
+    Returns (sel0, order, pos, seq_of_row, counts):
+      sel0        indices (into the K rows) of the type-0 rows
+      order       permutation of sel0-local rows, grouped by sequence
+      pos         position of each ordered row inside its sequence (0-based)
+      seq_of_row  sequence index of each ordered row
+      counts      rows per sequence (int64 [S])"""
+    sel0 = (types_c == 0).nonzero().view(-1)
+    ids0 = ids_c[sel0]
+    uniq, inv, counts = torch.unique(ids0, sorted=True, return_inverse=True, return_counts=True)
+    order = torch.argsort(inv, stable=True)
+    starts = torch.cumsum(counts, 0) - counts
+    seq_of_row = inv[order]
+    pos = torch.arange(order.numel()) - starts[seq_of_row]
+    return sel0, order, pos, seq_of_row, counts
+
+
 class MatchPredictor(nn.Module):
     def __init__(self):
         super().__init__()
@@ -128,20 +149,16 @@ class TemporalAggregationNLB(MatchPredictor):
             dev = x3.device
             types_c = torch.as_tensor(types).cpu()
             ids_c = torch.as_tensor(ids).cpu()
-            sel0 = (types_c == 0).nonzero().view(-1)
+            sel0, order, pos, seq_of_row, counts = plan_sequences(types_c, ids_c)
             x3_1_ids_c = ids_c[sel0]
             x3_2 = x3[(types_c == 1).to(dev)]
             if x3_1_ids_c.numel() > 0:
                 # packing rules: sequences ordered by sorted unique id; maxlen = modal count;
                 # dummy zero row 0; mask True on padding (ref :98-111)
-                uniq, inv, counts = torch.unique(x3_1_ids_c, sorted=True, return_inverse=True, return_counts=True)
-                n_seqs, maxlen = int(uniq.numel()), int(counts.max())
-                order = torch.argsort(inv, stable=True)                 # rows grouped by sequence, original order kept
-                starts = torch.cumsum(counts, 0) - counts
-                pos = torch.arange(order.numel()) - starts[inv[order]]    # position inside its sequence
+                n_seqs, maxlen = int(counts.numel()), int(counts.max())
                 x3_1_seq = torch.zeros((1 + maxlen, n_seqs, 256), device=dev, dtype=x3.dtype)
                 rows = x3[sel0[order].to(dev)]
-                x3_1_seq[(pos + 1).to(dev), inv[order].to(dev)] = rows
+                x3_1_seq[(pos + 1).to(dev), seq_of_row.to(dev)] = rows
                 x3_1_mask = (torch.arange(1 + maxlen)[None, :] > counts[:, None]).to(dev)
                 lens = counts.to(torch.int32).to(dev)
                 x3_1b, att = self.aggregate(x3_1_seq[1:], lens, getatt)

@@ -1,0 +1,150 @@
+"""CPU: the C-ABI library loads and exports every symbol include/seam_hip.h declares (no compute
+calls), and the host-side logic (sizes, anchors, sequence packing plan, sharding, state-dict
+keys) agrees with the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import seam_match_rcnn_amd.synth as synth
+from conftest import ROOT, to_torch
+from oracle import detection as OD
+from oracle import heads as OH
+
+
+@pytest.fixture(scope="module")
+def native():
+    from seam_match_rcnn_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "seam-match-rcnn_amd", "csrc"), "-j4"], check=True)
+    return _native
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "seam_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(seam_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(native):
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    lib = native.lib()
+    for s in syms:
+        assert hasattr(lib, s), f"libseam_hip.so does not export {s}"
+        assert s in native.SIGNATURES, f"{s} declared in seam_hip.h but not bound in _native.SIGNATURES"
+    assert sorted(native.SIGNATURES) == syms
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (seam_[a-z0-9_]+)", out))
+    assert exported == set(syms)
+
+
+def test_host_helpers_no_gpu(native):
+    lib = native.lib()
+    assert lib.seam_version() >= 1000
+    assert lib.seam_conv_kred(256, 3, 3) == 2304 and lib.seam_conv_kred(4, 7, 7) == 224
+    assert lib.seam_conv_rows_padded(15) == 64 and lib.seam_conv_rows_padded(256) == 256
+    assert lib.seam_nlb_workspace_floats(2, 10) >= 2 * 10 * 130
+
+
+def test_product_path_fails_loudly_without_gpu(native):
+    from seam_match_rcnn_amd import ops
+    from seam_match_rcnn_amd.models.match_head import MatchPredictor
+    with pytest.raises(native.SeamNativeError):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), None)
+    mp = MatchPredictor().eval()
+    with torch.no_grad(), pytest.raises(native.SeamNativeError):
+        mp(torch.zeros(2, 256, 14, 14), torch.IntTensor([0, 1]))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "seam-match-rcnn_amd")
+    for d, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+@pytest.mark.parametrize("hw", [(800, 800), (1080, 1920), (480, 640), (333, 500), (1200, 700)])
+def test_resized_size_matches_interpolate(hw):
+    from seam_match_rcnn_amd.models.detection import resized_size
+    h, w = hw
+    oh, ow, scale = resized_size(h, w)
+    ref = torch.nn.functional.interpolate(torch.zeros(1, 1, h, w), scale_factor=scale, mode="bilinear",
+                                          recompute_scale_factor=True, align_corners=False)
+    assert (oh, ow) == tuple(ref.shape[-2:]) == OD.resized_size(h, w)[:2]
+
+
+def test_grid_anchors_match_oracle_and_known_values():
+    from seam_match_rcnn_amd.models.detection import grid_anchors
+    feat = [(200, 200), (100, 100), (50, 50), (25, 25), (13, 13)]
+    got = grid_anchors((800, 800), feat)
+    ref = OD.grid_anchors((800, 800), feat)
+    assert sum(a.shape[0] for a in got) == 159882
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r.numpy())
+    # level 0, cell (0,0): ratios 0.5, 1, 2 of size 32 -> rounded half extents
+    assert got[0][:3].tolist() == [[-23., -11., 23., 11.], [-16., -16., 16., 16.], [-11., -23., 11., 23.]]
+    # 'pool' level stride is 800 // 13 = 61 (integer division quirk)
+    assert got[4][3].tolist() == [61. - 362., -181., 61. + 362., 181.]
+
+
+def test_sequence_plan_matches_reference_packing(golden):
+    from seam_match_rcnn_amd.models.match_head import plan_sequences
+    ids = torch.from_numpy(golden["ta_ids"])
+    types = torch.from_numpy(golden["ta_types"])
+    sel0, order, pos, seq_of_row, counts = plan_sequences(types, ids)
+    x3_1 = torch.arange(len(sel0), dtype=torch.float32)[:, None].repeat(1, 4)       # row tags
+    seq, mask, lst = OH.pack_sequences(x3_1, ids[sel0])
+    mine = torch.zeros_like(seq)
+    mine[pos + 1, seq_of_row] = x3_1[order]
+    assert torch.equal(mine, seq)
+    assert torch.equal((torch.arange(seq.shape[0])[None, :] > counts[:, None]), mask)
+    assert np.array_equal(mask.numpy(), golden["taA_x3_1_mask"])
+    assert np.array_equal(ids[sel0].numpy(), golden["taA_x3_1_ids"])
+
+
+def test_shard_helpers():
+    from seam_match_rcnn_amd.retrieval import clips_for_rank, shard_range
+    for n, w in [(1000, 1), (1000, 8), (50000, 8), (10, 4), (3, 8)]:
+        rs = [shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+        assert max(hi - lo for lo, hi in rs) - min(hi - lo for lo, hi in rs) <= 1
+    assert sorted(sum((clips_for_rank(64, r, 8) for r in range(8)), [])) == list(range(64))
+    assert clips_for_rank(64, 3, 8)[:3] == [3, 11, 19]
+
+
+def test_state_dict_keys_and_both_torchvision_layouts():
+    from seam_match_rcnn_amd.models.matchrcnn import matchrcnn_resnet50_fpn
+    from seam_match_rcnn_amd.models.video_matchrcnn import videomatchrcnn_resnet50_fpn
+    sd = to_torch(synth.video_matchrcnn_state(5))
+    m = videomatchrcnn_resnet50_fpn(pretrained_backbone=False, num_classes=14)
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd, strict=True)
+    new = {}
+    for k, v in sd.items():
+        k2 = k
+        if k.startswith("backbone.fpn."):
+            p = k.split(".")
+            k2 = ".".join(p[:4] + ["0"] + p[4:])
+        elif k.startswith("rpn.head.conv."):
+            k2 = k.replace("rpn.head.conv.", "rpn.head.conv.0.0.")
+        elif "mask_head.mask_fcn" in k:
+            i = int(k.split("mask_fcn")[1][0])
+            k2 = k.replace(f"mask_fcn{i}", f"{i - 1}.0")
+        new[k2] = v
+    m.load_state_dict(new, strict=True)                      # torchvision >= 0.13 key layout
+    # phase-1 -> phase-2 hand-off copies match_predictor into temporal_aggregator (ref :325-328)
+    m.load_saved_matchrcnn({k: v for k, v in sd.items() if "temporal_aggregator" not in k})
+    ta, mp = m.roi_heads.temporal_aggregator.state_dict(), m.roi_heads.match_predictor.state_dict()
+    assert all(torch.equal(ta[k], mp[k]) for k in mp)
+    assert m.roi_heads.temporal_aggregator.n_frames == -1 and m.roi_heads.temporal_aggregator.nlb is True
+    m1 = matchrcnn_resnet50_fpn(pretrained_backbone=False, num_classes=14)
+    assert not any("temporal_aggregator" in k for k in m1.state_dict())
+    with pytest.raises(NotImplementedError):
+        m.train()([torch.zeros(3, 32, 32)])
