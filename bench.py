@@ -143,7 +143,7 @@ def main():
             torch.cuda.synchronize()
             trace, ops.CONV_TRACE = ops.CONV_TRACE, None
         per = {}
-        for variant, flops, e0, e1 in trace:
+        for variant, flops, e0, e1, _shape in trace:
             a = per.setdefault(variant, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops

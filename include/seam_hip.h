@@ -44,8 +44,9 @@ const char* seam_error_string(int code);
  *   y[n,ho,wo,k] = act( scale[k] * sum_{r,s,c} x[n,ho*stride+r-pad,wo*stride+s-pad,c]
  *                                   * w[k][(r*S+s)*C+c]  + shift[k] + residual[n,ho,wo,k] )
  *
- * x        NHWC [N,H,W,C], C multiple of 4 (pad channels must be zero-weighted)
- * w_packed [rows_padded][kred] from seam_pack_conv_weight_f32 (K-contiguous rows)
+ * x        NHWC [N,H,W,C], C multiple of 4 and, when C >= 32, of 32 (pad channels zero-weighted)
+ * w_packed rows_padded*kred floats from seam_pack_conv_weight_f32 (tile-contiguous slabs
+ *          [n_tile][chunk][BN][32]; opaque to the caller)
  * scale    [K] or NULL (=1);  shift [K] or NULL (=0)   (bias / folded BatchNorm)
  * residual NHWC [N,Ho,Wo,K] or NULL, added before the activation
  * relu     0/1
@@ -54,8 +55,8 @@ const char* seam_error_string(int code);
 int seam_conv_kred(int C, int R, int S);           /* host helper: ceil(R*S*C / 32) * 32 */
 int seam_conv_rows_padded(int K);                  /* host helper: ceil(K / 64) * 64      */
 
-/* Pack an OIHW weight [K,Cin,R,S] (PyTorch layout) into [rows_padded][kred] with the
- * reduction index ordered (r,s,c), c < Cstore (channels >= Cin zero-filled).
+/* Pack an OIHW weight [K,Cin,R,S] (PyTorch layout) into the kernel's slab layout
+ * (rows_padded*kred floats; reduction chunks ordered (r, c-chunk, s); channels >= Cin zero-filled).
  * mode 0: Conv2d / Linear (Linear = R=S=1; fc6 = a 7x7 "valid" conv over the 7x7 ROI tile)
  * mode 1: ConvTranspose2d(k=2,s=2) weight [Cin,Cout,2,2] -> rows ((a*2+b)*Cout + co),
  *         i.e. a 1x1 conv producing the 4 sub-pixels as channel groups; K = 4*Cout.   */

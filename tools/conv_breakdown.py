@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-launch conv efficiency of one config-2 bench step (GPU box): shape, us, TFLOP/s."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from seam_match_rcnn_amd import ops, retrieval
+import seam_match_rcnn_amd.synth as synth
+
+dev = torch.device("cuda:0")
+model, sd = bench.build_model(dev)
+ta = model.roi_heads.temporal_aggregator
+T, R = bench.T, bench.R
+frames = list(torch.from_numpy(synth.frames(0, T, 800, 800)).to(dev).unbind(0))
+rois = [torch.from_numpy(synth.fixed_rois(R, 800, 800)).to(dev) for _ in range(T)]
+types = torch.zeros(T * R, dtype=torch.int32); ids = torch.arange(R).repeat(T)
+def step():
+    res, feats, rpn = model.forward_fixed_rois(frames, rois)
+    rf = torch.cat([r["roi_features"] for r in res])
+    return ta(rf, types, ids)
+with torch.no_grad():
+    step(); step(); torch.cuda.synchronize()
+    ops.CONV_TRACE = []
+    step(); torch.cuda.synchronize()
+    tr, ops.CONV_TRACE = ops.CONV_TRACE, None
+agg = {}
+for variant, fl, e0, e1, shp in tr:
+    a = agg.setdefault((variant[-9:], shp), [0, 0.0, 0.0]); a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
+tot = sum(v[2] for v in agg.values())
+print(f"{'variant':>10} {'N,H,W,C,K,R,s':>34} {'n':>3} {'ms':>8} {'%':>5} {'TF/s':>6}")
+for (v, shp), (n, fl, sec) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+    print(f"{v:>10} {str(shp):>34} {n:3d} {sec*1e3:8.3f} {100*sec/tot:5.1f} {fl/sec/1e12:6.1f}")
+print("total conv ms", tot * 1e3)
