@@ -265,6 +265,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
 
     // ---- epilogue: y = act(acc*scale + shift + residual) --------------------------------------
     // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Branch-free: residual loads / stores are raw buffer ops rebased at this tile's first row;
+    // rows >= M or cols >= K get an out-of-range offset (loads return 0, stores are dropped), so all
+    // residual loads of a wave are in flight together instead of one vmcnt(0) per element.
+    const size_t tile_off = (size_t)m0 * p.K;
+    const unsigned y_bytes = (unsigned)min((size_t)BM, (size_t)(p.M - m0)) * (unsigned)p.K * 4u;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + tile_off), 0, (int)y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.res ? p.res : p.y) + tile_off), 0, (int)y_bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wn0 + j * 32 + (lane & 31);
@@ -273,16 +281,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
         const float sh = (p.shift && nok) ? p.shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            unsigned off[16];
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (nok && m < p.M) {
-                    const size_t o = (size_t)m * p.K + n;
-                    float v = acc[i][j][r] * sc + sh;
-                    if (p.res) v += p.res[o];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[o] = v;
-                }
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                off[r] = nok ? (unsigned)(row * p.K + n) * 4u : kOob;      // rows >= M fall outside y_bytes
+            }
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off[r], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] * sc + sh;
+                if (p.res) v += rv[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, off[r], 0, 0);
             }
         }
     }
