@@ -143,16 +143,18 @@ def main():
             torch.cuda.synchronize()
             trace, ops.CONV_TRACE = ops.CONV_TRACE, None
         per = {}
-        for variant, flops, e0, e1, _shape in trace:
-            a = per.setdefault(variant, [0, 0.0, 0.0])
+        for variant, flops, e0, e1, _shape, nbytes in trace:
+            a = per.setdefault(variant, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += e0.elapsed_time(e1) * 1e-3
+            a[3] += nbytes
         dom = max(per, key=lambda k: per[k][2])
-        n, fl, sec = per[dom]
+        n, fl, sec, alg_bytes = per[dom]
         achieved = fl / sec / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": pmc_traffic(dom), "algorithmic_bytes_per_launch": round(alg_bytes / n),
                     "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
                     "conv_ms_per_step": round(1e3 * sum(v[2] for v in per.values()), 3),
@@ -186,6 +188,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+    produced by tools/pmc_bench_traffic.sh on this same bench command): FETCH_SIZE and WRITE_SIZE are
+    collected in separate passes, reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
+    coalesced reads, so the read side is doubled (MI355X_MICROARCH.md, HBM section).  None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return round((2.0 * d["FETCH_SIZE"][kernel]["avg_per_launch"] + d["WRITE_SIZE"][kernel]["avg_per_launch"]) * 1024)
+    except (KeyError, ValueError, OSError):
+        return None
 
 
 def usable_cores():

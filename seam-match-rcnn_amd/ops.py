@@ -123,7 +123,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         e1.record()
         variant = "conv_igemm_f32<128,128>" if pc.w.shape[0] % 128 == 0 else "conv_igemm_f32<128,64>"
         trace.append((variant, 2.0 * n * ho * wo * pc.K * pc.R * pc.S * (pc.Cin or pc.Cstore), e0, e1,
-                      (n, h, w, c, pc.K, pc.R, pc.stride)))
+                      (n, h, w, c, pc.K, pc.R, pc.stride),
+                      4.0 * (x.numel() + y.numel() * (2 if residual is not None else 1) + pc.w.numel())))
     return y
 
 

@@ -24,7 +24,7 @@ with torch.no_grad():
     step(); torch.cuda.synchronize()
     tr, ops.CONV_TRACE = ops.CONV_TRACE, None
 agg = {}
-for variant, fl, e0, e1, shp in tr:
+for variant, fl, e0, e1, shp, _b in tr:
     a = agg.setdefault((variant[-9:], shp), [0, 0.0, 0.0]); a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
 tot = sum(v[2] for v in agg.values())
 print(f"{'variant':>10} {'N,H,W,C,K,R,s':>34} {'n':>3} {'ms':>8} {'%':>5} {'TF/s':>6}")
