@@ -142,6 +142,14 @@ int seam_pair_logits_f32(const float* a, const float* b, const float* w, const f
 int seam_rank_topk_f32(const float* logits, int64_t* idx, float* score, int Q, int G, int k,
                        seam_stream_t stream);
 
+/* Fused pairwise logits + top-k (a13 + a14 in one pass; no [Q,G,2] round trip through HBM):
+ * same ranking rule and bit-identical x1-x0 as seam_pair_logits_f32 + seam_rank_topk_f32.
+ * k <= 256, k <= G; ws: >= seam_pair_topk_workspace_floats(Q,G,k) floats of scratch. */
+int64_t seam_pair_topk_workspace_floats(int Q, int G, int k);
+int seam_pair_topk_f32(const float* a, const float* b, const float* w, const float* bias,
+                       int64_t* idx, float* score, int Q, int G, int D, int k, float* ws,
+                       seam_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Detection post-processing [TV] + models/video_matchrcnn.py:154-205.
  * BoxCoder.decode (weights wx,wy,ww,wh; dw,dh clamped to log(1000/16)) + clip to image.

@@ -324,6 +324,177 @@ __global__ __launch_bounds__(256) void rank_topk_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused pair logits + top-k (no [Q,G,2] round trip through HBM): stage 1 computes a 32-query x
+// 256-product logit tile into LDS with the same register tiling / FMA order as pair_logits_kernel<4,4>
+// (so d = x1 - x0 is bit-identical to the unfused path) and selects the tile's k best per query;
+// stage 2 merges the per-segment candidates.  Candidate = (x0, x1, index).
+constexpr int TK_SEG = 256;
+
+__device__ __forceinline__ bool tk_better(float d, int g, float bd, int bg) { return d > bd || (d == bd && g < bg); }
+
+__global__ __launch_bounds__(256) void pair_topk_stage1(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ cand, int Q, int G, int Dd, int k, int nseg) {
+    constexpr int KC = 32, LD = KC + 4, BQ = 32, BG = 128;
+    __shared__ __attribute__((aligned(16))) float as[BQ * LD];
+    __shared__ __attribute__((aligned(16))) float bs[BG * LD];
+    __shared__ __attribute__((aligned(16))) float ws[2 * KC];
+    __shared__ float L0[BQ][TK_SEG + 1];
+    __shared__ float L1[BQ][TK_SEG + 1];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, lane = tid & 63, wid = tid >> 6;
+    const int seg = blockIdx.x, q0 = blockIdx.y * BQ, gseg = seg * TK_SEG;
+    const float b0 = bias[0], b1 = bias[1];
+    for (int sub = 0; sub < TK_SEG / BG; ++sub) {
+        const int g0 = gseg + sub * BG;
+        float acc0[4][4], acc1[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc0[i][j] = 0.f; acc1[i][j] = 0.f; }
+        for (int k0 = 0; k0 < Dd; k0 += KC) {
+            __syncthreads();
+            for (int i = tid; i < BQ * (KC / 4); i += 256) {
+                const int r = i / (KC / 4), c = i % (KC / 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (q0 + r < Q) v = *reinterpret_cast<const f32x4*>(a + (size_t)(q0 + r) * Dd + k0 + c * 4);
+                *reinterpret_cast<f32x4*>(&as[r * LD + c * 4]) = v;
+            }
+            for (int i = tid; i < BG * (KC / 4); i += 256) {
+                const int r = i / (KC / 4), c = i % (KC / 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (g0 + r < G) v = *reinterpret_cast<const f32x4*>(b + (size_t)(g0 + r) * Dd + k0 + c * 4);
+                *reinterpret_cast<f32x4*>(&bs[r * LD + c * 4]) = v;
+            }
+            if (tid < 2 * KC) ws[tid] = w[(size_t)(tid / KC) * Dd + k0 + (tid % KC)];
+            __syncthreads();
+#pragma unroll
+            for (int k4 = 0; k4 < KC; k4 += 4) {
+                f32x4 av[4], bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(&as[(ty * 4 + i) * LD + k4]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bs[(tx + 32 * j) * LD + k4]);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&ws[k4]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&ws[KC + k4]);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = av[i][kk] - bv[j][kk];
+                            const float d2 = d * d;
+                            acc0[i][j] = fmaf(d2, w0[kk], acc0[i][j]);
+                            acc1[i][j] = fmaf(d2, w1[kk], acc1[i][j]);
+                        }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                L0[ty * 4 + i][sub * BG + tx + 32 * j] = acc0[i][j] + b0;
+                L1[ty * 4 + i][sub * BG + tx + 32 * j] = acc1[i][j] + b1;
+            }
+    }
+    __syncthreads();
+    // selection: wave w owns queries w*8 .. w*8+7; k rounds of wave arg-max over the 256 columns
+    for (int qq = 0; qq < 8; ++qq) {
+        const int ql = wid * 8 + qq, q = q0 + ql;
+        if (q >= Q) break;
+        float dv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = lane + 64 * c;
+            float d = L1[ql][col] - L0[ql][col];
+            if (d != d || gseg + col >= G) d = -INFINITY;
+            dv[c] = d;
+        }
+        float pv = INFINITY;
+        int pg = -1;
+        for (int round = 0; round < k; ++round) {
+            float bd = -INFINITY;
+            int bg = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int g = gseg + lane + 64 * c;
+                const bool elig = g < G && ((dv[c] < pv) || (dv[c] == pv && g > pg));
+                if (elig && tk_better(dv[c], g, bd, bg)) { bd = dv[c]; bg = g; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float od = __shfl_xor(bd, o, 64);
+                const int og = __shfl_xor(bg, o, 64);
+                if (tk_better(od, og, bd, bg)) { bd = od; bg = og; }
+            }
+            if (lane == 0) {
+                float* c = cand + (((size_t)q * nseg + seg) * k + round) * 3;
+                const bool found = bg != 0x7fffffff;
+                c[0] = found ? L0[ql][bg - gseg] : 0.f;
+                c[1] = found ? L1[ql][bg - gseg] : -INFINITY;
+                c[2] = __int_as_float(found ? bg : -1);
+            }
+            pv = bd;
+            pg = bg;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_topk_stage2(const float* __restrict__ cand, int64_t* __restrict__ idx,
+                                                        float* __restrict__ score, int ncand, int k) {
+    __shared__ float rv[4];
+    __shared__ int ri[4], rc[4];
+    __shared__ float bestv;
+    __shared__ int besti, bestc;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* c = cand + (size_t)q * ncand * 3;
+    float pv = INFINITY;
+    int pi = -1;
+    for (int round = 0; round < k; ++round) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff, bc = -1;
+        for (int j = tid; j < ncand; j += 256) {
+            const int g = __float_as_int(c[j * 3 + 2]);
+            if (g < 0) continue;
+            float d = c[j * 3 + 1] - c[j * 3];
+            if (d != d) d = -INFINITY;
+            const bool elig = (d < pv) || (d == pv && g > pi);
+            if (elig && tk_better(d, g, bv, bi)) { bv = d; bi = g; bc = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            const int oc = __shfl_xor(bc, o, 64);
+            if (tk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; bc = oc; }
+        }
+        if (lane == 0) { rv[wid] = bv; ri[wid] = bi; rc[wid] = bc; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = rv[0];
+            int i = ri[0], cc = rc[0];
+            for (int w2 = 1; w2 < 4; ++w2)
+                if (tk_better(rv[w2], ri[w2], v, i)) { v = rv[w2]; i = ri[w2]; cc = rc[w2]; }
+            bestv = v; besti = i; bestc = cc;
+            const bool found = i != 0x7fffffff;
+            idx[(size_t)q * k + round] = found ? (int64_t)i : (int64_t)-1;
+            float sc = 0.f;
+            if (found) {
+                const float x0 = c[cc * 3], x1 = c[cc * 3 + 1];
+                const float mx = fmaxf(x0, x1);
+                const float e0 = expf(x0 - mx), e1 = expf(x1 - mx);
+                sc = e1 / (e0 + e1);
+            }
+            score[(size_t)q * k + round] = sc;
+        }
+        __syncthreads();
+        pv = bestv;
+        pi = besti;
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -357,6 +528,22 @@ int seam_pair_logits_f32(const float* a, const float* b, const float* w, const f
         hipLaunchKernelGGL((pair_logits_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, b, w, bias, out,
                            Q, G, Dd);
     }
+    return (int)hipGetLastError();
+}
+
+int64_t seam_pair_topk_workspace_floats(int Q, int G, int k) {
+    const int64_t nseg = (G + TK_SEG - 1) / TK_SEG;
+    return (int64_t)Q * nseg * k * 3 + 16;
+}
+
+int seam_pair_topk_f32(const float* a, const float* b, const float* w, const float* bias, int64_t* idx, float* score,
+                       int Q, int G, int Dd, int k, float* ws, void* stream) {
+    if (Q <= 0 || k <= 0) return 0;
+    if (k > G || k > TK_SEG || (Dd % 32)) return (int)hipErrorInvalidValue;
+    const int nseg = (G + TK_SEG - 1) / TK_SEG;
+    hipLaunchKernelGGL(pair_topk_stage1, dim3(nseg, (Q + 31) / 32), dim3(256), 0, (hipStream_t)stream, a, b, w, bias, ws,
+                       Q, G, Dd, k, nseg);
+    hipLaunchKernelGGL(pair_topk_stage2, dim3(Q), dim3(256), 0, (hipStream_t)stream, ws, idx, score, nseg * k, k);
     return (int)hipGetLastError();
 }
 

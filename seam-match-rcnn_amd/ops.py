@@ -275,6 +275,21 @@ def rank_topk(logits: torch.Tensor, k: int):
     return idx, sc
 
 
+def pair_topk(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, k: int):
+    """Fused a13+a14: top-k products per query without materialising [Q,G,2].
+    -> (idx int64 [Q,k], score [Q,k])."""
+    lib = _native.lib()
+    a, b, w, bias = _req(a), _req(b), _req(w.detach()), _req(bias.detach())
+    q, g, d = a.shape[0], b.shape[0], a.shape[1]
+    k = min(k, g)
+    idx = torch.empty((q, k), dtype=torch.int64, device=a.device)
+    sc = torch.empty((q, k), dtype=F32, device=a.device)
+    ws = torch.empty((int(lib.seam_pair_topk_workspace_floats(q, g, k)),), dtype=F32, device=a.device)
+    _native.check(lib.seam_pair_topk_f32(_ptr(a), _ptr(b), _ptr(w), _ptr(bias), _ptr(idx), _ptr(sc), q, g, d, k, _ptr(ws),
+                                         _stream()), "seam_pair_topk_f32")
+    return idx, sc
+
+
 # ------------------------------------------------------------------------------ detection
 def decode_boxes(deltas: torch.Tensor, boxes: torch.Tensor, weights, clip_hw=None) -> torch.Tensor:
     """deltas [N,ncls*4], boxes [N,4] -> [N,ncls*4]; optional clip to (h,w)."""

@@ -107,3 +107,12 @@ def match_sequences(aggregator, x3_1b: torch.Tensor, bank: torch.Tensor, k: int 
     x5 = aggregator.pair(x3_1b, bank)
     idx, score = ops.rank_topk(x5, min(k, bank.shape[0]))
     return x5, idx, score
+
+
+@torch.no_grad()
+def match_sequences_topk(aggregator, x3_1b: torch.Tensor, bank: torch.Tensor, k: int = 20):
+    """Same ranking as ``match_sequences`` without materialising the [S,G,2] logits (fused
+    ``seam_pair_topk_f32``): for large galleries (configs 3/4: G = 20 000 / 50 000) the logits tensor
+    is the dominant HBM traffic of the stage.  -> (idx [S,k] int64, score [S,k])."""
+    from . import ops
+    return ops.pair_topk(x3_1b, bank, aggregator.last.weight, aggregator.last.bias, min(k, bank.shape[0]))

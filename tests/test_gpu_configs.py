@@ -1,0 +1,112 @@
+"""GPU parity at the BASELINE.json config sizes that are not the bench line (configs 3, 4, 5):
+full-size runs checked against the oracle where it finishes in seconds, otherwise through
+size-independent properties (fused == unfused exactly, permutation equivariance, checksums)."""
+import numpy as np
+import pytest
+import torch
+
+import seam_match_rcnn_amd.synth as synth
+from conftest import to_torch
+from oracle import detection as OD
+from oracle import heads as OH
+from test_gpu_ops import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ta():
+    from seam_match_rcnn_amd.models.match_head import TemporalAggregationNLB
+    m = TemporalAggregationNLB()
+    p = to_torch(synth.temporal_aggregator_state(12))
+    m.load_state_dict(p)
+    return m.to(dev()).eval(), p
+
+
+def test_config3_mode_b_8clips_20000_gallery(ta):
+    """config 3: 8 clips x 32 sequences x 10 frames vs a 20 000-product gallery (Mode B)."""
+    from seam_match_rcnn_amd import ops, retrieval
+    m, p = ta
+    s, t, g = 256, 10, 20000
+    seq = torch.zeros((1 + t, s, 256))
+    seq[1:] = torch.from_numpy(synth.normal(synth.stream_id(301, "seq"), (t, s, 256)))
+    mask = torch.zeros((s, 1 + t), dtype=torch.bool)
+    gal = torch.from_numpy(synth.gallery(302, g))
+    with torch.no_grad():
+        out = m(None, None, None, x3_1_seq=seq.to(dev()), x3_1_mask=mask.to(dev()), x3_2=gal.to(dev()))
+    x3_1b, x5 = out[0], out[2]
+    assert x5.shape == (s, g, 2)
+    ref_b, _ = OH.aggregate_sequences([seq[1:, i] for i in range(s)], p)
+    assert_close(x3_1b, ref_b)
+    ref5 = OH.pair_logits(ref_b, gal, p["last.weight"], p["last.bias"], chunk=16)
+    assert_close(x5, ref5)
+    # checksum of checksums (fp64) over the 41 MB logits tensor
+    assert abs(float(x5.double().sum()) - float(ref5.double().sum())) <= 1e-5 * float(ref5.double().abs().sum())
+    idx, sc = ops.rank_topk(x5, 20)
+    ridx, rsc = OH.rank_topk(x5.cpu(), 20)
+    assert torch.equal(idx.cpu(), ridx)
+    fidx, fsc = retrieval.match_sequences_topk(m, x3_1b, gal.to(dev()), 20)      # fused: no [S,G,2] in HBM
+    assert torch.equal(fidx, idx) and torch.equal(fsc, sc)
+    oidx, _ = OH.rank_topk(ref5, 20)
+    agree = np.mean([len(set(a.tolist()) & set(b.tolist())) / 20.0 for a, b in zip(idx.cpu(), oidx)])
+    assert agree > 0.995, agree
+
+
+def test_config4_shard_sized_match_50000_gallery(ta):
+    """config 4 (per-rank view): 256 local sequences vs the all-gathered 50 000-product bank.
+    Full oracle on a query sample; fused/unfused exact equality and gallery-permutation
+    equivariance on everything."""
+    from seam_match_rcnn_amd import ops, retrieval
+    m, p = ta
+    q, g = 256, 50000
+    a = torch.from_numpy(synth.normal(synth.stream_id(401, "a"), (q, 256)))
+    bank = torch.from_numpy(synth.gallery(402, g))
+    ad, bd = a.to(dev()), bank.to(dev())
+    x5, idx, sc = retrieval.match_sequences(m, ad, bd, 20)
+    fidx, fsc = retrieval.match_sequences_topk(m, ad, bd, 20)
+    assert torch.equal(fidx, idx) and torch.equal(fsc, sc)
+    sel = [0, 17, 101, 255]
+    ref = OH.pair_logits(a[sel], bank, p["last.weight"], p["last.bias"], chunk=2)
+    assert_close(x5[sel], ref)
+    # permuting the gallery permutes the ranking (scores unchanged; ties are measure-zero here)
+    perm = torch.from_numpy(np.random.RandomState(0).permutation(g))
+    pidx, psc = retrieval.match_sequences_topk(m, ad, bd[perm.to(dev())], 20)
+    assert torch.equal(perm.to(dev())[pidx], idx)
+    assert torch.equal(psc, sc)
+    # small-k / k == G edge cases of the fused kernel
+    i1, s1 = ops.pair_topk(ad[:3], bd[:7], m.last.weight, m.last.bias, 7)
+    i2, s2 = ops.rank_topk(ops.pair_logits(ad[:3], bd[:7], m.last.weight, m.last.bias), 7)
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+
+
+def test_config5_shapes_fp32(ta):
+    """config 5 shapes (30-frame clips, 64 ROI/frame, 1080p) on the fp32 path: sequences of T=30
+    through NLB+pool, and one 1080p frame through resize + stem/layer1 against the oracle.
+    (The fp16-MFMA variant named by config 5 is not built yet; fp32 is the stricter result.)"""
+    from seam_match_rcnn_amd import ops
+    from seam_match_rcnn_amd.models.detection import GeneralizedRCNNTransform, ResNet50Body
+    m, p = ta
+    s, t = 64, 30
+    x = torch.from_numpy(synth.normal(synth.stream_id(501, "x"), (t, s, 256)))
+    out, att = m.aggregate(x.to(dev()), torch.full((s,), t, dtype=torch.int32, device=dev()), want_att=True)
+    ref, atts = OH.aggregate_sequences([x[:, i] for i in range(s)], p)
+    assert_close(out, ref)
+    assert_close(att[5], atts[5][:, 0])
+    img = torch.from_numpy(synth.frames(50, 1, 1080, 1920)[0])
+    tr = GeneralizedRCNNTransform()
+    xb, sizes, orig = tr([img.to(dev())])
+    rb, rsz = OD.transform([img])
+    assert [tuple(z) for z in rsz] == [tuple(z) for z in sizes] and xb.shape[1:3] == rb.shape[-2:]
+    assert_close(xb[..., :3].permute(0, 3, 1, 2), rb, atol_scale=1e-5)
+    sd = to_torch({k: v for k, v in synth.detector_state(5).items() if k.startswith("backbone.body.")})
+    body = ResNet50Body()
+    body.load_state_dict({k[len("backbone.body."):]: v for k, v in sd.items()})
+    body = body.to(dev())
+    feats = body(xb)
+    rf = OD.resnet50_body(rb, sd)
+    assert_close(feats[0].permute(0, 3, 1, 2), rf[0])
+    assert_close(feats[3].permute(0, 3, 1, 2), rf[3])
