@@ -158,11 +158,17 @@ int seam_decode_boxes_f32(const float* deltas, const float* boxes_in, float* box
                           int ncls, float wx, float wy, float ww, float wh, float clip_h,
                           float clip_w, seam_stream_t stream);
 
-/* Greedy NMS over boxes ALREADY SORTED by descending score: keep[i]=1/0 (int32 [N]).
- * IoU > thr suppresses (strict), areas without +1.  Bitmask formulation, N <= 8192.
- * mask_ws: uint64 workspace of N*ceil(N/64) words. */
-int seam_nms_sorted_f32(const float* boxes, int* keep, int N, float thr, uint64_t* mask_ws,
+/* Greedy NMS, batched over B images, over boxes [B,N,4] ALREADY SORTED by descending score inside
+ * each image: keep[b,i]=1/0 (int32 [B,N]).  IoU > thr suppresses (strict), areas without +1.
+ * 64x64 bitmask tiles + one-wave scan per image, N <= 16384.
+ * mask_ws: uint64 workspace of B*N*ceil(N/64) words. */
+int seam_nms_sorted_f32(const float* boxes, int* keep, int B, int N, float thr, uint64_t* mask_ws,
                         seam_stream_t stream);
+
+/* paste_masks_in_image [TV] (transform.postprocess, reached from model(images)): masks [K,1,28,28]
+ * probabilities, boxes [K,4] (original-image px) -> out [K,1,H,W]. */
+int seam_paste_masks_f32(const float* masks, const float* boxes, float* out, int K, int H, int W,
+                         seam_stream_t stream);
 
 /* maskrcnn_inference [TV] (call models/video_matchrcnn.py:291): logits laid out
  * [K,14,14,(a,b),ncls] (sub-pixel groups from the transposed conv) -> prob [K,1,28,28] of the

@@ -44,7 +44,8 @@ SIGNATURES = {
     "seam_pair_topk_workspace_floats": (_i64, [_i, _i, _i]),
     "seam_pair_topk_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "seam_decode_boxes_f32": (_i, [_p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _p]),
-    "seam_nms_sorted_f32": (_i, [_p, _p, _i, _f, _p, _p]),
+    "seam_nms_sorted_f32": (_i, [_p, _p, _i, _i, _f, _p, _p]),
+    "seam_paste_masks_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "seam_mask_select_f32": (_i, [_p, _p, _p, _i, _i, _p]),
 }
 

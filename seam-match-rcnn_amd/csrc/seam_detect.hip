@@ -34,6 +34,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
                                                       int N, float thr) {
     const int ib = blockIdx.y, jb = blockIdx.x;
     if (jb < ib) return;
+    boxes += (size_t)blockIdx.z * N * 4;                 // batch (image) index
+    mask += (size_t)blockIdx.z * N * gridDim.x;
     __shared__ float4 cb[64];
     const int t = threadIdx.x;
     const int j = jb * 64 + t;
@@ -56,15 +58,19 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     mask[(size_t)i * gridDim.x + jb] = bits;
 }
 
-// one wave: walk the 64-box blocks in order; resolve each diagonal block with scalar bit ops, then
-// OR the kept rows into the running "removed" words (lane l owns words l, l+64, ... of <= 128 words).
+// one wave per image: walk the 64-box blocks in order; resolve each diagonal block with scalar bit ops,
+// then OR the kept rows into the running "removed" words (lane l owns words l, l+64, l+128, l+192 of
+// <= 256 words, i.e. N <= 16384).
 __global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict__ mask, int* __restrict__ keep,
                                                       int N, int nb) {
     const int lane = threadIdx.x;
-    uint64_t rem0 = 0, rem1 = 0;   // removed bits of words lane, lane+64
+    mask += (size_t)blockIdx.x * N * nb;
+    keep += (size_t)blockIdx.x * N;
+    uint64_t rem0 = 0, rem1 = 0, rem2 = 0, rem3 = 0;   // removed bits of words lane, lane+64, lane+128, lane+192
     for (int blk = 0; blk < nb; ++blk) {
         // removed word of this block lives in lane (blk & 63), slot (blk >> 6)
-        const uint64_t mine = (blk >> 6) ? rem1 : rem0;
+        const int slot = blk >> 6;
+        const uint64_t mine = slot == 0 ? rem0 : slot == 1 ? rem1 : slot == 2 ? rem2 : rem3;
         uint64_t removed = __shfl(mine, blk & 63, 64);
         const int i = blk * 64 + lane;
         const uint64_t diag = i < N ? mask[(size_t)i * nb + blk] : 0ull;
@@ -86,6 +92,8 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict
             const size_t rowoff = (size_t)(blk * 64 + b) * nb;
             if (lane > blk && lane < nb) rem0 |= mask[rowoff + lane];
             if (lane + 64 > blk && lane + 64 < nb) rem1 |= mask[rowoff + lane + 64];
+            if (lane + 128 > blk && lane + 128 < nb) rem2 |= mask[rowoff + lane + 128];
+            if (lane + 192 > blk && lane + 192 < nb) rem3 |= mask[rowoff + lane + 192];
         }
     }
 }
@@ -104,6 +112,42 @@ __global__ void mask_select_kernel(const float* __restrict__ logits, const int64
     prob[i] = 1.f / (1.f + expf(-v));
 }
 
+// paste_masks_in_image [TV]: mask prob [K,1,28,28] zero-padded to 30x30, box expanded by 30/28 and
+// truncated to int, bilinear (align_corners=False) resize of the padded map to the integer box size,
+// pasted into [K,1,H,W] (zeros elsewhere).  One thread per output pixel quad.
+__global__ void paste_masks_kernel(const float* __restrict__ masks, const float* __restrict__ boxes,
+                                   float* __restrict__ out, int K, int H, int W) {
+    const int k = blockIdx.y;
+    const float4 bx = reinterpret_cast<const float4*>(boxes)[k];
+    const float scale = 30.f / 28.f;
+    const float wh = (bx.z - bx.x) * 0.5f * scale, hh = (bx.w - bx.y) * 0.5f * scale;
+    const float xc = (bx.z + bx.x) * 0.5f, yc = (bx.w + bx.y) * 0.5f;
+    const int x0 = (int)(xc - wh), y0 = (int)(yc - hh), x1 = (int)(xc + wh), y1 = (int)(yc + hh);   // trunc toward 0 (int64 cast)
+    const int bw = max(x1 - x0 + 1, 1), bh = max(y1 - y0 + 1, 1);
+    const float sx = 30.f / (float)bw, sy = 30.f / (float)bh;
+    const float* m = masks + (size_t)k * 784;
+    float* o = out + (size_t)k * H * W;
+    const int total = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        float v = 0.f;
+        const int ry = y - y0, rx = x - x0;
+        if (ry >= 0 && ry < bh && rx >= 0 && rx < bw && y <= y1 && x <= x1) {
+            float fy = sy * ((float)ry + 0.5f) - 0.5f, fx = sx * ((float)rx + 0.5f) - 0.5f;
+            if (fy < 0.f) fy = 0.f;
+            if (fx < 0.f) fx = 0.f;
+            int iy = min((int)fy, 29), ix = min((int)fx, 29);
+            const int iy1 = iy < 29 ? iy + 1 : iy, ix1 = ix < 29 ? ix + 1 : ix;
+            const float ly = fminf(fmaxf(fy - (float)iy, 0.f), 1.f), lx = fminf(fmaxf(fx - (float)ix, 0.f), 1.f);
+            auto at = [&](int yy, int xx) -> float {      // 30x30 zero-padded view of the 28x28 map
+                return (yy >= 1 && yy <= 28 && xx >= 1 && xx <= 28) ? m[(yy - 1) * 28 + (xx - 1)] : 0.f;
+            };
+            v = (1.f - ly) * ((1.f - lx) * at(iy, ix) + lx * at(iy, ix1)) + ly * ((1.f - lx) * at(iy1, ix) + lx * at(iy1, ix1));
+        }
+        o[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -117,12 +161,20 @@ int seam_decode_boxes_f32(const float* deltas, const float* boxes_in, float* box
     return (int)hipGetLastError();
 }
 
-int seam_nms_sorted_f32(const float* boxes, int* keep, int N, float thr, uint64_t* mask_ws, void* stream) {
-    if (N <= 0) return 0;
-    if (N > 8192) return (int)hipErrorInvalidValue;
+int seam_nms_sorted_f32(const float* boxes, int* keep, int B, int N, float thr, uint64_t* mask_ws, void* stream) {
+    if (N <= 0 || B <= 0) return 0;
+    if (N > 16384 || B > 65535) return (int)hipErrorInvalidValue;
     const int nb = (N + 63) / 64;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, (hipStream_t)stream, boxes, mask_ws, N, thr);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mask_ws, keep, N, nb);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, B), dim3(64), 0, (hipStream_t)stream, boxes, mask_ws, N, thr);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask_ws, keep, N, nb);
+    return (int)hipGetLastError();
+}
+
+int seam_paste_masks_f32(const float* masks, const float* boxes, float* out, int K, int H, int W, void* stream) {
+    if (K <= 0) return 0;
+    int gx = (H * W + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(paste_masks_kernel, dim3(gx, K), dim3(256), 0, (hipStream_t)stream, masks, boxes, out, K, H, W);
     return (int)hipGetLastError();
 }
 

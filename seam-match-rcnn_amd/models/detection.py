@@ -273,14 +273,37 @@ def grid_anchors(padded_hw, feat_hws, sizes=(32, 64, 128, 256, 512)) -> List[np.
 
 
 def batched_nms(boxes, scores, idxs, thr):
-    """torchvision ``batched_nms`` (coordinate-offset form) -> kept indices by descending score.
-    The IoU/suppression bit-matrix and the greedy scan are HIP kernels; the sort is a device sort."""
+    """torchvision ``batched_nms`` (coordinate-offset form) for ONE image -> kept indices by descending
+    score.  The IoU bit-matrix and the greedy scan are HIP kernels; the sort is a device sort."""
     if boxes.numel() == 0:
         return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
     off = idxs.to(boxes) * (boxes.max() + 1.0)
     order = torch.argsort(scores, descending=True, stable=True)
     keep = ops.nms_sorted((boxes + off[:, None])[order].contiguous(), thr)
     return order[keep.bool()]
+
+
+def batched_nms_images(boxes, scores, idxs, valid, thr, top_n):
+    """``batched_nms`` for a whole batch of images in one set of launches.
+
+    boxes [B,n,4], scores [B,n], idxs [B,n] (class / level id), valid [B,n] bool (entries removed by
+    the score / small-box filters).  Per image: offset boxes by idx*(max_coord+1) (max over the
+    image's valid boxes, as torchvision computes it on the filtered set), sort by score (stable,
+    descending), greedy NMS, keep the first ``top_n`` survivors.
+    -> (order [B,n] int64: candidate index at each sorted position, sel [B,n] bool: sorted positions
+    that survive).  No host synchronisation."""
+    neg = torch.finfo(boxes.dtype).min
+    mx = torch.where(valid[..., None], boxes, boxes.new_full((), neg)).amax(dim=(1, 2))            # [B]
+    off = idxs.to(boxes) * (mx[:, None] + 1.0)
+    sc = torch.where(valid, scores, scores.new_full((), -1.0))                                      # invalid sort last
+    order = torch.argsort(sc, dim=1, descending=True, stable=True)
+    sb = torch.gather(boxes + off[..., None], 1, order[..., None].expand(-1, -1, 4))
+    sv = torch.gather(valid, 1, order)
+    # invalid entries become far-away degenerate boxes: they suppress nothing and are masked out below
+    sb = torch.where(sv[..., None], sb, sb.new_full((), -1.0e8)).contiguous()
+    keep = ops.nms_sorted(sb, thr).bool() & sv
+    rank = torch.cumsum(keep.to(torch.int32), 1)
+    return order, keep & (rank <= top_n)
 
 
 class RegionProposalNetwork(nn.Module):
@@ -299,27 +322,36 @@ class RegionProposalNetwork(nn.Module):
         return self._anchor_cache[key]
 
     def forward(self, feats: "OrderedDict[str, torch.Tensor]", image_sizes, padded_hw):
+        """RegionProposalNetwork.filter_proposals for the whole batch: per-level top-k (batched over
+        images), decode + clip, sigmoid, small-box filter, per-level NMS, first post_nms_top_n --
+        one host synchronisation (the variable-length split of the result) instead of ~20 per image."""
         fl = list(feats.values())
         head = self.head(fl)
         n = fl[0].shape[0]
-        anchors = self.anchors(padded_hw, [f.shape[1:3] for f in fl], fl[0].device)
-        props = []
-        for b in range(n):                                      # RegionProposalNetwork.filter_proposals
-            bx, sc, lv = [], [], []
-            for l, ((obj, dlt), anc) in enumerate(zip(head, anchors)):
-                o = obj[b].reshape(-1)
-                k = min(self.pre_nms_top_n, o.numel())
-                top = torch.argsort(o, descending=True, stable=True)[:k]    # ties -> lower index
-                d = dlt[b].reshape(-1, 4)[top].contiguous()
-                bx.append(ops.decode_boxes(d, anc[top].contiguous(), (1.0, 1.0, 1.0, 1.0), image_sizes[b]))
-                sc.append(torch.sigmoid(o[top]))
-                lv.append(torch.full((k,), l, dtype=torch.int64, device=o.device))
-            bx, sc, lv = torch.cat(bx), torch.cat(sc), torch.cat(lv)
-            keep = ((bx[:, 2] - bx[:, 0]) >= self.min_size) & ((bx[:, 3] - bx[:, 1]) >= self.min_size)
-            bx, sc, lv = bx[keep], sc[keep], lv[keep]
-            keep = batched_nms(bx, sc, lv, self.nms_thresh)[:self.post_nms_top_n]
-            props.append(bx[keep])
-        return props
+        dev = fl[0].device
+        anchors = self.anchors(padded_hw, [f.shape[1:3] for f in fl], dev)
+        bx, sc, lv = [], [], []
+        same_size = all(tuple(s) == tuple(image_sizes[0]) for s in image_sizes)
+        for l, ((obj, dlt), anc) in enumerate(zip(head, anchors)):
+            o = obj.reshape(n, -1)
+            k = min(self.pre_nms_top_n, o.shape[1])
+            top = torch.argsort(o, dim=1, descending=True, stable=True)[:, :k]          # ties -> lower index
+            d = torch.gather(dlt.reshape(n, -1, 4), 1, top[..., None].expand(-1, -1, 4)).reshape(n * k, 4)
+            a = anc[top.reshape(-1)]
+            if same_size:
+                b = ops.decode_boxes(d.contiguous(), a.contiguous(), (1.0, 1.0, 1.0, 1.0), image_sizes[0])
+            else:
+                b = torch.cat([ops.decode_boxes(d[i * k:(i + 1) * k].contiguous(), a[i * k:(i + 1) * k].contiguous(),
+                                                (1.0, 1.0, 1.0, 1.0), image_sizes[i]) for i in range(n)])
+            bx.append(b.view(n, k, 4))
+            sc.append(torch.sigmoid(torch.gather(o, 1, top)))
+            lv.append(torch.full((n, k), l, dtype=torch.int64, device=dev))
+        bx, sc, lv = torch.cat(bx, 1), torch.cat(sc, 1), torch.cat(lv, 1)
+        valid = ((bx[..., 2] - bx[..., 0]) >= self.min_size) & ((bx[..., 3] - bx[..., 1]) >= self.min_size)
+        order, sel = batched_nms_images(bx, sc, lv, valid, self.nms_thresh, self.post_nms_top_n)
+        kept = torch.gather(bx, 1, order[..., None].expand(-1, -1, 4))
+        counts = sel.sum(1).tolist()                                                    # the one sync
+        return list(kept[sel].split(counts, 0))
 
 
 # ------------------------------------------------------------------------------ RoIAlign (a7)
@@ -455,25 +487,8 @@ def maskrcnn_inference(mask_logits_sub, labels: Sequence[torch.Tensor], num_clas
 
 
 def paste_masks_in_image(masks: torch.Tensor, boxes: torch.Tensor, img_hw, padding: int = 1) -> torch.Tensor:
-    """transform.postprocess mask paste [TV] -> [K,1,H,W].  The output is read by no caller of the
-    reference (stuffs/engine.py:15,118; evaluate_movingfashion.py never touches ``masks``); it is
-    produced for output-dict parity with device tensor ops (not a HIP kernel; outside the timed path)."""
-    import torch.nn.functional as F
-    m = masks.shape[-1]
-    scale = float(m + 2 * padding) / m
-    pm = F.pad(masks, (padding,) * 4)
-    wh = (boxes[:, 2] - boxes[:, 0]) * 0.5 * scale
-    hh = (boxes[:, 3] - boxes[:, 1]) * 0.5 * scale
-    xc = (boxes[:, 2] + boxes[:, 0]) * 0.5
-    yc = (boxes[:, 3] + boxes[:, 1]) * 0.5
-    eb = torch.stack((xc - wh, yc - hh, xc + wh, yc + hh), 1).to(torch.int64).cpu().tolist()
-    im_h, im_w = img_hw
-    out = masks.new_zeros((masks.shape[0], 1, im_h, im_w))
-    for i, b in enumerate(eb):
-        w, h = max(b[2] - b[0] + 1, 1), max(b[3] - b[1] + 1, 1)
-        r = F.interpolate(pm[i][None], size=(h, w), mode="bilinear", align_corners=False)[0, 0]
-        x0, x1 = max(b[0], 0), min(b[2] + 1, im_w)
-        y0, y1 = max(b[1], 0), min(b[3] + 1, im_h)
-        if x1 > x0 and y1 > y0:
-            out[i, 0, y0:y1, x0:x1] = r[(y0 - b[1]):(y1 - b[1]), (x0 - b[0]):(x1 - b[0])]
-    return out
+    """transform.postprocess mask paste [TV] -> [K,1,H,W] (``seam_paste_masks_f32``).  Read by no caller of
+    the reference (stuffs/engine.py:15,118; evaluate_movingfashion.py never touches ``masks``); produced
+    for output-dict parity."""
+    assert padding == 1 and masks.shape[-1] == 28
+    return ops.paste_masks(masks.contiguous(), boxes.to(torch.float32).contiguous(), img_hw)

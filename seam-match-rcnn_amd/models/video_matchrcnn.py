@@ -67,24 +67,36 @@ class TemporalRoIHeads(nn.Module):
     def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes):
         num_classes = class_logits.shape[-1]
         counts = [len(p) for p in proposals]
-        pred_scores = F.softmax(class_logits, -1).split(counts, 0)
-        regs = box_regression.split(counts, 0)
-        all_boxes, all_scores, all_labels = [], [], []
-        for reg, scores, props, shape in zip(regs, pred_scores, proposals, image_shapes):
-            dev = scores.device
-            boxes = ops.decode_boxes(reg.contiguous(), props.contiguous(), (10.0, 10.0, 5.0, 5.0), shape)
-            boxes = boxes.view(-1, num_classes, 4)
-            labels = torch.arange(num_classes, device=dev).view(1, -1).expand_as(scores)
-            boxes, scores, labels = boxes[:, 1:].reshape(-1, 4), scores[:, 1:].flatten(), labels[:, 1:].flatten()
-            inds = torch.nonzero(scores > self.score_thresh).squeeze(1)
-            boxes, scores, labels = boxes[inds], scores[inds], labels[inds]
-            keep = ((boxes[:, 2] - boxes[:, 0]) >= 1e-2) & ((boxes[:, 3] - boxes[:, 1]) >= 1e-2)
-            boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
-            keep = det.batched_nms(boxes, scores, labels, self.nms_thresh)[:self.detections_per_img]
-            all_boxes.append(boxes[keep])
-            all_scores.append(scores[keep])
-            all_labels.append(labels[keep])
-        return all_boxes, all_scores, all_labels
+        n_img = len(counts)
+        if n_img == 0 or max(counts) == 0:
+            e = class_logits.new_zeros((0,))
+            return ([e.view(0, 4)] * n_img, [e] * n_img, [e.to(torch.int64)] * n_img)
+        dev = class_logits.device
+        pred_scores = F.softmax(class_logits, -1)
+        # decode + clip (HIP); images of one batch normally share a size, else decode per image
+        if all(tuple(s) == tuple(image_shapes[0]) for s in image_shapes):
+            boxes = ops.decode_boxes(box_regression.contiguous(), torch.cat(proposals).contiguous(),
+                                     (10.0, 10.0, 5.0, 5.0), image_shapes[0])
+        else:
+            boxes = torch.cat([ops.decode_boxes(r.contiguous(), p.contiguous(), (10.0, 10.0, 5.0, 5.0), s)
+                               for r, p, s in zip(box_regression.split(counts, 0), proposals, image_shapes)])
+        # pad every image to the same number of proposals so the whole batch is filtered at once
+        pmax = max(counts)
+        c = (num_classes - 1) * pmax
+        pb = boxes.new_zeros((n_img, pmax, num_classes, 4))
+        ps = pred_scores.new_full((n_img, pmax, num_classes), -1.0)
+        row = torch.cat([torch.arange(k, device=dev) for k in counts])
+        img = torch.repeat_interleave(torch.arange(n_img, device=dev), torch.tensor(counts, device=dev))
+        pb[img, row] = boxes.view(-1, num_classes, 4)
+        ps[img, row] = pred_scores
+        pb, ps = pb[:, :, 1:].reshape(n_img, c, 4), ps[:, :, 1:].reshape(n_img, c)           # drop background
+        labels = torch.arange(1, num_classes, device=dev).repeat(pmax)[None].expand(n_img, -1)
+        valid = (ps > self.score_thresh) & ((pb[..., 2] - pb[..., 0]) >= 1e-2) & ((pb[..., 3] - pb[..., 1]) >= 1e-2)
+        order, sel = det.batched_nms_images(pb, ps, labels, valid, self.nms_thresh, self.detections_per_img)
+        kb = torch.gather(pb, 1, order[..., None].expand(-1, -1, 4))
+        ks, kl = torch.gather(ps, 1, order), torch.gather(labels, 1, order)
+        kept = sel.sum(1).tolist()                                                           # one sync
+        return (list(kb[sel].split(kept, 0)), list(ks[sel].split(kept, 0)), list(kl[sel].split(kept, 0)))
 
     def detect(self, features, proposals, image_shapes):
         """box branch (ref :225-253)."""

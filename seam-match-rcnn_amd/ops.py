@@ -304,17 +304,29 @@ def decode_boxes(deltas: torch.Tensor, boxes: torch.Tensor, weights, clip_hw=Non
 
 
 def nms_sorted(boxes: torch.Tensor, thr: float) -> torch.Tensor:
-    """boxes [N,4] already sorted by descending score -> keep mask int32 [N]."""
+    """boxes [N,4] or [B,N,4], already sorted by descending score (per image) -> keep mask int32 [N] / [B,N]."""
     boxes = _req(boxes)
-    n = boxes.shape[0]
-    keep = torch.empty((n,), dtype=torch.int32, device=boxes.device)
-    if n == 0:
-        return keep
-    nb = (n + 63) // 64
-    ws = torch.empty((n * nb,), dtype=torch.int64, device=boxes.device)
-    _native.check(_native.lib().seam_nms_sorted_f32(_ptr(boxes), _ptr(keep), n, float(thr), _ptr(ws), _stream()),
-                  "seam_nms_sorted_f32")
-    return keep
+    single = boxes.dim() == 2
+    b3 = boxes[None] if single else boxes
+    bsz, n = b3.shape[0], b3.shape[1]
+    keep = torch.empty((bsz, n), dtype=torch.int32, device=boxes.device)
+    if n and bsz:
+        nb = (n + 63) // 64
+        ws = torch.empty((bsz * n * nb,), dtype=torch.int64, device=boxes.device)
+        _native.check(_native.lib().seam_nms_sorted_f32(_ptr(b3), _ptr(keep), bsz, n, float(thr), _ptr(ws), _stream()),
+                      "seam_nms_sorted_f32")
+    return keep[0] if single else keep
+
+
+def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, hw) -> torch.Tensor:
+    """masks [K,1,28,28] prob, boxes [K,4] original-image px -> [K,1,H,W]."""
+    masks, boxes = _req(masks), _req(boxes)
+    k = masks.shape[0]
+    out = torch.empty((k, 1, int(hw[0]), int(hw[1])), dtype=F32, device=masks.device)
+    if k:
+        _native.check(_native.lib().seam_paste_masks_f32(_ptr(masks), _ptr(boxes), _ptr(out), k, int(hw[0]), int(hw[1]),
+                                                         _stream()), "seam_paste_masks_f32")
+    return out
 
 
 def mask_select(logits: torch.Tensor, labels: torch.Tensor, ncls: int) -> torch.Tensor:
