@@ -142,6 +142,14 @@ int seam_pair_logits_f32(const float* a, const float* b, const float* w, const f
 int seam_rank_topk_f32(const float* logits, int64_t* idx, float* score, int Q, int G, int k,
                        seam_stream_t stream);
 
+/* Evaluator-side scoring.  score = softmax(logits)[...,1] for n_pairs rows of 2
+ * (compute_distances / compute_selfdist, evaluate_movingfashion.py:102-121);  rank[q] = position of
+ * product target[q] in the descending ranking of query q (what `(rankings == shop_prod_index)
+ * .nonzero()` extracts at evaluate_movingfashion.py:228,268), same tie rule as seam_rank_topk_f32. */
+int seam_match_scores_f32(const float* logits, float* score, int64_t n_pairs, seam_stream_t stream);
+int seam_rank_of_f32(const float* logits, const int64_t* target, int64_t* rank, int Q, int G,
+                     seam_stream_t stream);
+
 /* Fused pairwise logits + top-k (a13 + a14 in one pass; no [Q,G,2] round trip through HBM):
  * same ranking rule and bit-identical x1-x0 as seam_pair_logits_f32 + seam_rank_topk_f32.
  * k <= 256, k <= G; ws: >= seam_pair_topk_workspace_floats(Q,G,k) floats of scratch. */

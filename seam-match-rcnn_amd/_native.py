@@ -41,6 +41,8 @@ SIGNATURES = {
     "seam_nlb_attnpool_f32": (_i, [_p, _i64, _i64, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "seam_pair_logits_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "seam_rank_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "seam_match_scores_f32": (_i, [_p, _p, _i64, _p]),
+    "seam_rank_of_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_pair_topk_workspace_floats": (_i64, [_i, _i, _i]),
     "seam_pair_topk_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "seam_decode_boxes_f32": (_i, [_p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _p]),

@@ -495,6 +495,43 @@ __global__ __launch_bounds__(256) void pair_topk_stage2(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Evaluator-side helpers: softmax(x)[...,1] of a logits matrix, and the rank of
+// one target column per query under the same strict order as rank_topk (score desc, index asc).
+__global__ void match_scores_kernel(const float* __restrict__ logits, float* __restrict__ score, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 x = reinterpret_cast<const float2*>(logits)[i];
+        const float mx = fmaxf(x.x, x.y);
+        const float e0 = expf(x.x - mx), e1 = expf(x.y - mx);
+        score[i] = e1 / (e0 + e1);
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_of_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                      int64_t* __restrict__ rank, int G) {
+    __shared__ int part[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float2* row = reinterpret_cast<const float2*>(logits) + (size_t)q * G;
+    const int t = (int)target[q];
+    int cnt = 0;
+    if (t >= 0 && t < G) {
+        const float2 xt = row[t];
+        float dt = xt.y - xt.x;
+        if (dt != dt) dt = -INFINITY;
+        for (int g = tid; g < G; g += 256) {
+            const float2 x = row[g];
+            float d = x.y - x.x;
+            if (d != d) d = -INFINITY;
+            cnt += (d > dt || (d == dt && g < t)) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) rank[q] = (t >= 0 && t < G) ? (int64_t)(part[0] + part[1] + part[2] + part[3]) : (int64_t)-1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -528,6 +565,20 @@ int seam_pair_logits_f32(const float* a, const float* b, const float* w, const f
         hipLaunchKernelGGL((pair_logits_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, b, w, bias, out,
                            Q, G, Dd);
     }
+    return (int)hipGetLastError();
+}
+
+int seam_match_scores_f32(const float* logits, float* score, int64_t n_pairs, void* stream) {
+    if (n_pairs <= 0) return 0;
+    int grid = (int)((n_pairs + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(match_scores_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, score, (size_t)n_pairs);
+    return (int)hipGetLastError();
+}
+
+int seam_rank_of_f32(const float* logits, const int64_t* target, int64_t* rank, int Q, int G, void* stream) {
+    if (Q <= 0) return 0;
+    hipLaunchKernelGGL(rank_of_kernel, dim3(Q), dim3(256), 0, (hipStream_t)stream, logits, target, rank, G);
     return (int)hipGetLastError();
 }
 

@@ -275,6 +275,24 @@ def rank_topk(logits: torch.Tensor, k: int):
     return idx, sc
 
 
+def match_scores(logits: torch.Tensor) -> torch.Tensor:
+    """logits [...,2] -> softmax(logits)[...,1]."""
+    logits = _req(logits)
+    out = torch.empty(logits.shape[:-1], dtype=F32, device=logits.device)
+    _native.check(_native.lib().seam_match_scores_f32(_ptr(logits), _ptr(out), out.numel(), _stream()),
+                  "seam_match_scores_f32")
+    return out
+
+
+def rank_of(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """logits [Q,G,2], target int64 [Q] -> rank int64 [Q] of the target product in each query's ranking."""
+    logits, target = _req(logits), _req(target, torch.int64, "target")
+    q, g = logits.shape[0], logits.shape[1]
+    out = torch.empty((q,), dtype=torch.int64, device=logits.device)
+    _native.check(_native.lib().seam_rank_of_f32(_ptr(logits), _ptr(target), _ptr(out), q, g, _stream()), "seam_rank_of_f32")
+    return out
+
+
 def pair_topk(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, k: int):
     """Fused a13+a14: top-k products per query without materialising [Q,G,2].
     -> (idx int64 [Q,k], score [Q,k])."""

@@ -116,3 +116,24 @@ def match_sequences_topk(aggregator, x3_1b: torch.Tensor, bank: torch.Tensor, k:
     is the dominant HBM traffic of the stage.  -> (idx [S,k] int64, score [S,k])."""
     from . import ops
     return ops.pair_topk(x3_1b, bank, aggregator.last.weight, aggregator.last.bias, min(k, bank.shape[0]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Evaluator-side retrieval on the device in fp32 (SURVEY.md 8f row f1): the closures of
+# evaluate_movingfashion.py:94-121 (NumPy fp16, full argsort per query on the CPU) as kernel calls.
+@torch.no_grad()
+def compute_distances(street: torch.Tensor, shop: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``compute_distances`` / ``compute_selfdist`` (pass shop=street): softmax((shop-street)^2 @ w.T + b)[...,1]
+    -> [n_street, n_shop]  (ref evaluate_movingfashion.py:102-107,115-121)."""
+    from . import ops
+    return ops.match_scores(ops.pair_logits(street, shop, w, b))
+
+
+@torch.no_grad()
+def compute_rank_of(street: torch.Tensor, shop: torch.Tensor, w: torch.Tensor, b: torch.Tensor,
+                    target: torch.Tensor) -> torch.Tensor:
+    """Rank of the true product of each street descriptor: what the evaluator extracts from
+    ``compute_ranking(inds)`` with ``(rankings == shop_prod_index).nonzero()`` (ref :94-100,228,268); the
+    top-k accuracies only test ``rank < k`` for k in {1,5,10,20} (ref :15,229-231)."""
+    from . import ops
+    return ops.rank_of(ops.pair_logits(street, shop, w, b), target.to(torch.int64))

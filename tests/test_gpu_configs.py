@@ -110,3 +110,23 @@ def test_config5_shapes_fp32(ta):
     rf = OD.resnet50_body(rb, sd)
     assert_close(feats[0].permute(0, 3, 1, 2), rf[0])
     assert_close(feats[3].permute(0, 3, 1, 2), rf[3])
+
+
+def test_evaluator_side_scores_and_rank(ta):
+    """row f1: device-side compute_distances / compute_selfdist / rank-of-true-product vs the oracle."""
+    from seam_match_rcnn_amd import retrieval
+    m, p = ta
+    street = torch.from_numpy(synth.normal(synth.stream_id(601, "s"), (37, 256)))
+    shop = torch.from_numpy(synth.gallery(602, 501))
+    w, b = p["last.weight"], p["last.bias"]
+    ref5 = OH.pair_logits(street, shop, w, b)
+    sc = retrieval.compute_distances(street.to(dev()), shop.to(dev()), w.to(dev()), b.to(dev()))
+    assert_close(sc, OH.match_scores(ref5), atol_scale=1e-5)
+    self_sc = retrieval.compute_distances(street.to(dev()), street.to(dev()), w.to(dev()), b.to(dev()))
+    assert_close(self_sc, OH.match_scores(OH.pair_logits(street, street, w, b)), atol_scale=1e-5)
+    target = torch.arange(37) * 13 % 501
+    rk = retrieval.compute_rank_of(street.to(dev()), shop.to(dev()), w.to(dev()), b.to(dev()), target.to(dev()))
+    order = torch.argsort(ref5[..., 1] - ref5[..., 0], dim=1, descending=True, stable=True)
+    ref_rank = (order == target[:, None]).nonzero()[:, 1]
+    assert int((rk.cpu() - ref_rank).abs().max()) <= 1          # fp paths may swap one near-tie
+    assert float((rk.cpu() == ref_rank).float().mean()) > 0.9
