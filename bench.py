@@ -14,7 +14,7 @@ N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); every rank
 clip per step (weak scaling) and *owns* 1000/N rows of the product bank, which are all-gathered
 on a side stream each step before the match.  Rank 0 prints ONE JSON line.
 
-Extra legs (rank 0, N == 1 only): `roofline` for the dominant kernel (conv_igemm_f32<128,128>,
+Extra legs (rank 0, N == 1 only): `roofline` for the dominant kernel (conv_igemm<float,128,128>,
 bound = fp32 MFMA) from HIP events bracketing every launch of one instrumented step, and
 `cpu_baseline` = the CPU oracle timed on the host cores for one clip.
 """

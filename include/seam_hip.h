@@ -68,6 +68,18 @@ int seam_conv2d_f32(const float* x, const float* w_packed, const float* scale,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     int relu, seam_stream_t stream);
 
+/* fp16 variant (BASELINE config 5: "fp16 MFMA path with fp32 ... accumulation"): x, w_packed,
+ * residual are IEEE fp16 (NHWC, C multiple of 8 and, when C >= 64, of 64); v_mfma_f32_32x32x16_f16
+ * with fp32 accumulators; scale/shift stay fp32; y is fp16, or fp32 when y_f32 != 0 (the last trunk
+ * Linear hands fp32 descriptors to the fp32 heads).  Weights come from seam_pack_conv_weight_f16
+ * (source still the fp32 OIHW parameter; rows_padded * seam_conv_kred_f16(C,R,S) halves). */
+int seam_conv_kred_f16(int C, int R, int S);
+int seam_pack_conv_weight_f16(const float* w, void* w_packed, int K, int Cin, int R, int S,
+                              int Cstore, int mode, seam_stream_t stream);
+int seam_conv2d_f16(const void* x, const void* w_packed, const float* scale, const float* shift,
+                    const void* residual, void* y, int N, int H, int W, int C, int K, int R, int S,
+                    int stride, int pad, int relu, int y_f32, seam_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * GeneralizedRCNNTransform [TV] (reached from GeneralizedRCNN.forward; callers
  * stuffs/engine.py:115, evaluate_movingfashion.py:31): per image
@@ -77,12 +89,21 @@ int seam_conv2d_f32(const float* x, const float* w_packed, const float* scale,
 int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int out_h, int out_w,
                         int Hp, int Wp, seam_stream_t stream);
 
+int seam_preprocess_f16(const float* img, void* out /* fp16 NHWC8 */, int in_h, int in_w, int out_h,
+                        int out_w, int Hp, int Wp, seam_stream_t stream);
+
 /* max_pool2d on NHWC [TV: ResNet stem 3x3/s2/p1; LastLevelMaxPool k=1,s=2]. C % 4 == 0. */
 int seam_maxpool2d_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride,
                        int pad, seam_stream_t stream);
 
+int seam_maxpool2d_f16(const void* x, void* y, int N, int H, int W, int C, int k, int stride,
+                       int pad, seam_stream_t stream);   /* fp16, C % 8 == 0 */
+
 /* FPN top-down [TV]: lat[n,h,w,:] += top[n, floor(h*Ht/H), floor(w*Wt/W), :] (nearest). */
 int seam_upsample_add_f32(float* lat, const float* top, int N, int H, int W, int Ht, int Wt, int C,
+                          seam_stream_t stream);
+
+int seam_upsample_add_f16(void* lat, const void* top, int N, int H, int W, int Ht, int Wt, int C,
                           seam_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
@@ -98,12 +119,23 @@ int seam_roi_align_f32(const float* feat0, const float* feat1, const float* feat
                        const float* rois, const int* levels, float* out, int K, int P,
                        int sampling_ratio, seam_stream_t stream);
 
+int seam_roi_align_f16(const void* feat0, const void* feat1, const void* feat2, const void* feat3,
+                       const int* hw, int C, float scale0, float scale1, float scale2, float scale3,
+                       int k_min, const float* rois, const int* levels, void* out, int K, int P,
+                       int sampling_ratio, seam_stream_t stream);   /* fp16 maps in, fp16 out */
+
 /* Layout bridges at the module boundary: x [B,C,L] <-> y [B,L,C]. */
 int seam_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int L, seam_stream_t stream);
 int seam_nhwc_to_nchw_f32(const float* x, float* y, int B, int L, int C, seam_stream_t stream);
 
+/* fp16 path: the reference-facing side stays fp32 NCHW, the library side is fp16 NHWC. */
+int seam_nchw_f32_to_nhwc_f16(const float* x, void* y, int B, int C, int L, seam_stream_t stream);
+int seam_nhwc_f16_to_nchw_f32(const void* x, float* y, int B, int L, int C, seam_stream_t stream);
+
 /* AvgPool2d((6,6)) (+ no-op ReLU) of models/match_head.py:59-60: x [K,L,C] -> y [K,C]. */
 int seam_avgpool_f32(const float* x, float* y, int K, int L, int C, seam_stream_t stream);
+
+int seam_avgpool_f16(const void* x, void* y, int K, int L, int C, seam_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * NONLocalBlock1D(256, sub_sample=False, bn_layer=False) + attention pooling, batched
@@ -183,6 +215,9 @@ int seam_paste_masks_f32(const float* masks, const float* boxes, float* out, int
  * channel labels[k] (int64), after sigmoid. */
 int seam_mask_select_f32(const float* logits, const int64_t* labels, float* prob, int K, int ncls,
                          seam_stream_t stream);
+
+int seam_mask_select_f16(const void* logits, const int64_t* labels, float* prob, int K, int ncls,
+                         seam_stream_t stream);   /* fp16 logits in, fp32 probabilities out */
 
 #ifdef __cplusplus
 }

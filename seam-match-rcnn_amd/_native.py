@@ -30,7 +30,18 @@ SIGNATURES = {
     "seam_conv_rows_padded": (_i, [_i]),
     "seam_pack_conv_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv_kred_f16": (_i, [_i, _i, _i]),
+    "seam_pack_conv_weight_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv2d_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_preprocess_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_maxpool2d_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_upsample_add_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_roi_align_f16": (_i, [_p, _p, _p, _p, C.POINTER(_i), _i, _f, _f, _f, _f, _i, _p, _p, _p, _i, _i, _i, _p]),
+    "seam_nchw_f32_to_nhwc_f16": (_i, [_p, _p, _i, _i, _i, _p]),
+    "seam_nhwc_f16_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "seam_avgpool_f16": (_i, [_p, _p, _i, _i, _i, _p]),
+    "seam_mask_select_f16": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_maxpool2d_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_upsample_add_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_roi_align_f32": (_i, [_p, _p, _p, _p, C.POINTER(_i), _i, _f, _f, _f, _f, _i, _p, _p, _p, _i, _i, _i, _p]),

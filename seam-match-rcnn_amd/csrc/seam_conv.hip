@@ -1,61 +1,74 @@
-// seam_conv.hip -- implicit-GEMM convolution on gfx950, exact fp32 on the matrix cores.
+// seam_conv.hip -- implicit-GEMM convolution on gfx950 matrix cores: exact fp32 (the default path)
+// and fp16-in / fp32-accumulate (the path BASELINE config 5 names).
 //
 // One kernel family serves every dense contraction of the path (ResNet-50 body, FPN, RPN head,
 // box/mask heads, the match trunk's valid 3x3 convs and its Linear) -- see include/seam_hip.h.
 //
 // GEMM view (TN):  Y[M, K] = A[M, kred] * B[K, kred]^T
 //   M    = N*Ho*Wo output pixels, row m -> (n, ho, wo)          (NHWC output == row-major [M][K])
-//   kred = reduction index, walked in 32-wide chunks ordered (r, c-chunk, s) [C >= 32] so the three
-//          horizontal taps of one (row, channel-chunk) are consecutive chunks and re-hit the same
-//          A lines in L1; A is gathered on the fly from the NHWC input (hardware zero fill for
-//          padding / tails); B = pre-packed weights, stored TILE-CONTIGUOUS: [n_tile][chunk][BN][32]
-//          (one 16 KiB slab per chunk: no power-of-two row stride, no set conflicts, 4 TLB pages).
+//   kred = reduction index, walked in 128-BYTE chunks (32 floats / 64 halves) ordered
+//          (r, c-chunk, s) [C >= one chunk], so the horizontal taps of one (row, channel-chunk) are
+//          consecutive chunks; A is gathered on the fly from the NHWC input (hardware zero fill for
+//          padding / tails); B = pre-packed weights, TILE-CONTIGUOUS: [n_tile][chunk][BN][128 B]
+//          (one 16 KiB slab per chunk: no power-of-two row stride, 4 TLB pages).
 // Tiling for CDNA4 (wave64, 4 SIMDs/CU):
-//   block 256 threads = 4 waves (2x2); block tile BM x BN x 32; wave tile (BM/2) x (BN/2) built
-//   from 32x32 v_mfma_f32_32x32x2_f32 tiles (16 accumulator VGPRs each, 64 cyc/issue = the fp32 rate;
-//   bit-exact fp32 fma chain).  Operands go global -> registers -> LDS (rows padded to 36 floats:
-//   9 x 16 B slots, odd => ds_read_b128 / ds_write_b128 lane groups are conflict-free), double
-//   buffered, next chunk's global loads in flight under the current chunk's 64 MFMAs per wave.
-//   A fragment: lane l reads row (l&31), k-quad (l>>5): one ds_read_b128 feeds 4 MFMAs
-//   (k-pairs {j, j+4}); the same permutation is applied to B, so the contraction is unchanged.
-//   blockIdx -> tile mapping is XCD-aware: consecutive tiles (same A rows, neighbouring halos)
-//   stay on one XCD's L2 (dispatch is round-robin b % 8, guide T1, bijective form).
+//   block 256 threads = 4 waves (2x2); block tile BM x BN x (128 B of k); wave tile (BM/2) x (BN/2)
+//   of 32x32 MFMA tiles (16 accumulator VGPRs each):
+//     fp32: v_mfma_f32_32x32x2_f32  (64 cyc/issue = the fp32 rate; bit-exact fp32 fma chain)
+//     fp16: v_mfma_f32_32x32x16_f16 (fp32 accumulate)
+//   Both operand types share ONE byte layout: an LDS row is 128 B of k + 16 B pad (9 x 16-B slots,
+//   odd => ds_read_b128 / ds_write_b128 lane groups are conflict-free); lane l reads 16 B of row
+//   (l&31) at k-slot (l>>5): 4 floats feed 4 fp32 MFMAs (k-pairs {j, j+4}, same permutation on A
+//   and B), 8 halves feed 1 fp16 MFMA.
+//   Pipeline: raw buffer loads (SGPR descriptor, 32-bit lane offsets, hardware OOB zero fill) ->
+//   registers -> LDS, double-buffered LDS, TWO register sets (loads issued during chunk t are for
+//   chunk t+2) with counted vmcnt, fragments double-buffered ACROSS the chunk barrier, every
+//   load / LDS write unconditional (a branch around a load makes hipcc serialise it behind
+//   vmcnt(0)).  Epilogue: scale/shift (bias / folded BN) + residual + ReLU, branch-free buffer ops.
+//   blockIdx -> tile mapping is XCD-aware (consecutive tiles stay on one XCD's L2; bijective form).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;   // padded LDS row (floats)
+constexpr int CHUNK_BYTES = 128;                    // k bytes per row per chunk
+constexpr int LDB = CHUNK_BYTES + 16;               // padded LDS row (bytes)
+constexpr unsigned kOob = 0x80000000u;
 
 struct ConvArgs {
-    const float* x;
-    const float* w;
+    const void* x;
+    const void* w;
     const float* scale;
     const float* shift;
-    const float* res;
-    float* y;
+    const void* res;
+    void* y;
     int N, H, W, C;
     int Ho, Wo, K;
     int R, S, stride, pad;
-    int kred;
+    int kred;          // padded reduction length in elements (multiple of the chunk)
     int M;
     int relu;
+    int y_f32;         // fp16 kernel only: write fp32 output (descriptor heads stay fp32)
     int tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int V = 0>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
+    constexpr bool F16 = sizeof(T) == 2;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int EPV = 16 / ES;                 // elements per 16-byte vector (4 / 8)
+    constexpr int BKE = CHUNK_BYTES / ES;        // k elements per chunk (32 / 64)
     constexpr int WM = BM / 2, WN = BN / 2;      // wave tile
     constexpr int MT = WM / 32, NT = WN / 32;    // 32x32 MFMA tiles per wave
-    constexpr int AI = BM / 32, BI = BN / 32;    // float4 loads per thread per chunk
+    constexpr int AI = BM / 32, BI = BN / 32;    // 16-byte loads per thread per chunk
+    constexpr int Q = (F16 ? 1 : 4) * MT * NT;   // MFMAs per k-slot (32 B of k per row)
 
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) char As[2][BM * LDB];
+    __shared__ __attribute__((aligned(16))) char Bs[2][BN * LDB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,31 +80,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
     const int nblk = gridDim.x;
     const int b = blockIdx.x;
     const int xcd = b & 7;
-    const int q = nblk >> 3, rem = nblk & 7;
-    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+    const int q8 = nblk >> 3, rem = nblk & 7;
+    const int tile = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (b >> 3);
     const int tm = tile / p.tiles_n;
     const int tn = tile - tm * p.tiles_n;
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
     // ---- loader state -------------------------------------------------------------------------
-    // Both operands are fetched with raw buffer loads (SGPR descriptor + 32-bit lane offset): no
-    // 64-bit address math in the loop, and an out-of-image tap / tail row simply uses an offset
-    // beyond num_records, for which the hardware returns zeros (no select, no branch).
     // The A descriptor is rebased at the first image of this tile so lane offsets stay < 2 GiB for
     // any batch size (a 128-row tile never spans 2 GiB of input).
-    constexpr unsigned kOob = 0x80000000u;
-    const int nk = p.kred / BK;
-    const int lcol = tid & 7;     // which float4 of the 32-wide k chunk
+    const int nk = p.kred / BKE;
+    const int lcol = tid & 7;     // which 16-byte vector of the chunk
     const int lrow = tid >> 3;    // 0..31
     const int HoWo = p.Ho * p.Wo;
     const int n_first = m0 / HoWo;
     const size_t img_elems = (size_t)p.H * p.W * p.C;
-    const size_t rem_bytes = ((size_t)(p.N - n_first) * img_elems) * sizeof(float);
+    const size_t rem_bytes = ((size_t)(p.N - n_first) * img_elems) * ES;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.x + (size_t)n_first * img_elems), 0, (int)(rem_bytes > kOob ? kOob : (unsigned)rem_bytes), 0x00020000);
+        (void*)((const char*)p.x + (size_t)n_first * img_elems * ES), 0,
+        (int)(rem_bytes > kOob ? kOob : (unsigned)rem_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.w + (size_t)n0 * p.kred), 0, (int)((unsigned)BN * (unsigned)p.kred * 4u), 0x00020000);   // tile tn
+        (void*)((const char*)p.w + (size_t)n0 * p.kred * ES), 0, (int)((unsigned)BN * (unsigned)p.kred * ES), 0x00020000);
 
     int arow[AI], ahi[AI], awi[AI];      // byte offset of the (r=0,s=0,c=0) tap; top-left input coordinate
 #pragma unroll
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
             const int wo = rm - ho * p.Wo;
             ahi[i] = ho * p.stride - p.pad;
             awi[i] = wo * p.stride - p.pad;
-            arow[i] = ((((n - n_first) * p.H + ahi[i]) * p.W + awi[i]) * p.C) * 4;
+            arow[i] = ((((n - n_first) * p.H + ahi[i]) * p.W + awi[i]) * p.C) * ES;
         } else {
             ahi[i] = -(1 << 28);
             awi[i] = 0;
@@ -113,57 +123,53 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
     }
     int brow[BI];
 #pragma unroll
-    for (int i = 0; i < BI; ++i) brow[i] = ((lrow + 32 * i) * BK + lcol * 4) * 4;     // inside a [BN][32] slab
+    for (int i = 0; i < BI; ++i) brow[i] = (lrow + 32 * i) * CHUNK_BYTES + lcol * 16;     // inside a [BN][128 B] slab
 
-    // (r, s, c) of this thread's float4 inside the chunk being fetched, and its byte offset.
-    // C >= 32: chunks are walked (r, c-chunk, s) -- exactly the order of the packed weight slabs.
+    // (r, s, c) of this thread's 16-byte vector inside the chunk being fetched, and its byte offset.
+    // C >= one chunk: chunks are walked (r, c-chunk, s) -- exactly the order of the packed slabs.
     int kc, kr, ks, tapoff;
     {
-        const int kk = lcol * 4;
-        const int pos = kk / p.C;          // C >= 32: pos = 0
+        const int kk = lcol * EPV;
+        const int pos = kk / p.C;          // C >= BKE: pos = 0
         kc = kk - pos * p.C;
         kr = pos / p.S;
         ks = pos - kr * p.S;
-        tapoff = ((kr * p.W + ks) * p.C + kc) * 4;
+        tapoff = ((kr * p.W + ks) * p.C + kc) * ES;
     }
     // Number of the chunk being fetched.  Derived from kernel arguments only, so the weight-slab
     // offset below is provably wave-uniform (an SGPR soffset; a lane-tainted value would put every
     // buffer load into a waterfall loop).  Chunks >= nk are fetched too, but out of range: the
-    // loads stay UNCONDITIONAL (a branch around a load makes hipcc wait vmcnt(0) right behind it,
-    // serialising the whole prefetch), the hardware returns zeros and nobody reads them.
+    // loads stay UNCONDITIONAL, the hardware returns zeros and nobody reads them.
     int uq = 0;
 
-    // Two register sets: the loads issued during chunk t are for chunk t+2 (a whole chunk of
-    // MFMAs of slack before they are written to LDS during chunk t+1).
+    // Two register sets: the loads issued during chunk t are for chunk t+2 (a whole chunk of MFMAs
+    // of slack before they are written to LDS during chunk t+1).
     f32x4 areg0[AI], breg0[BI], areg1[AI], breg1[BI];
     auto load_a = [&](f32x4 (&ar)[AI], int i) {
         const bool ok = (unsigned)(ahi[i] + kr) < (unsigned)p.H && (unsigned)(awi[i] + ks) < (unsigned)p.W && kr < p.R;
-        unsigned off = ok ? (unsigned)(arow[i] + tapoff) : kOob;
-        if (V & 16) off = lcol * 16;            // dev ablation: A always hits the same 128 B line
-        if (V & 1) off = kOob;                  // dev ablation: no A traffic
+        const unsigned off = ok ? (unsigned)(arow[i] + tapoff) : kOob;
         ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
     };
     auto load_b = [&](f32x4 (&br)[BI], int i) {
-        const int so = uq < nk ? uq * (BN * BK * 4) : (int)kOob;
-        br[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (V & 32) ? lcol * 16 : brow[i],
-                                                                               (V & 32) ? 0 : so, 0));
+        const int so = uq < nk ? uq * (BN * CHUNK_BYTES) : (int)kOob;
+        br[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, brow[i], so, 0));
     };
     auto advance_k = [&]() {     // move on by one chunk
         ++uq;
-        if (p.C >= BK) {            // chunk order (r, c-chunk, s)
+        if (p.C >= BKE) {           // chunk order (r, c-chunk, s)
             if (++ks == p.S) {
                 ks = 0;
-                kc += BK;
+                kc += BKE;
                 if (kc >= p.C) { kc -= p.C; ++kr; }
             }
         } else {                    // small C (stem): (r, s, c) order, several taps per chunk
-            kc += BK;
+            kc += BKE;
             while (kc >= p.C) {
                 kc -= p.C;
                 if (++ks == p.S) { ks = 0; ++kr; }
             }
         }
-        tapoff = ((kr * p.W + ks) * p.C + kc) * 4;
+        tapoff = ((kr * p.W + ks) * p.C + kc) * ES;
     };
     auto load_chunk = [&](f32x4 (&ar)[AI], f32x4 (&br)[BI]) {
 #pragma unroll
@@ -172,13 +178,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
         for (int i = 0; i < BI; ++i) load_b(br, i);
         advance_k();
     };
-    auto store_chunk = [&](const f32x4 (&ar)[AI], const f32x4 (&br)[BI], int buf) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * i) * LDK + lcol * 4]) = ar[i];
-#pragma unroll
-        for (int i = 0; i < BI; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * i) * LDK + lcol * 4]) = br[i];
+    auto store_row = [&](const f32x4 (&ar)[AI], const f32x4 (&br)[BI], int buf, int r) {
+        if (r < AI) *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * r) * LDB + lcol * 16]) = ar[r];
+        else *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * (r - AI)) * LDB + lcol * 16]) = br[r - AI];
     };
 
     f32x16 acc[MT][NT];
@@ -189,78 +191,78 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int frow = lane & 31;
-    const int fk = (lane >> 5) * 4;
-    const int aoff = (wm0 + frow) * LDK + fk;
-    const int boff = (wn0 + frow) * LDK + fk;
+    const int aoff = (wm0 + (lane & 31)) * LDB + (lane >> 5) * 16;
+    const int boff = (wn0 + (lane & 31)) * LDB + (lane >> 5) * 16;
 
-    // Fragment sets are double buffered ACROSS the chunk barrier: while the MFMAs of k-step j run,
-    // the ds_reads of k-step j+1 are in flight; the next chunk is written to the other LDS buffer
-    // in the middle of k-step 2, the barrier sits before k-step 3, and the first fragments of the
-    // next chunk are fetched right behind it -- so a wave never waits on LDS with an idle MFMA pipe.
+    // Fragment sets are double buffered ACROSS the chunk barrier: while the MFMAs of k-slot j run,
+    // the ds_reads of k-slot j+1 are in flight; the next chunk is written to the other LDS buffer
+    // during k-slot 2, the barrier sits before k-slot 3, and the first fragments of the next chunk
+    // are fetched right behind it -- a wave never waits on LDS with an idle MFMA pipe.
     f32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
     auto read_frags = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT], int buf, int k8) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&As[buf][aoff + i * 32 * LDK + k8 * 8]);
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&As[buf][aoff + i * 32 * LDB + k8 * 32]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][boff + j * 32 * LDK + k8 * 8]);
+        for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][boff + j * 32 * LDB + k8 * 32]);
     };
-    // One chunk of the K loop.  `ld*`: register set receiving chunk t+2; `st*`: set holding chunk t+1.
-    // Every side operation (buffer load, LDS write) is placed behind its own MFMA: a VMEM / wide DS
-    // instruction costs tens of issue cycles, and two of them back to back leave the matrix pipe
-    // idle (the next MFMA of an in-order wave cannot issue until they are out).
-    constexpr int Q = 4 * MT * NT;               // MFMAs per k-step
     auto mf = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT], int idx) {
         const int kk = idx / (MT * NT), i = (idx / NT) % MT, j = idx % NT;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+        if constexpr (F16) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]),
+                                                               acc[i][j], 0, 0, 0);
+        } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+        }
     };
-    auto store_row = [&](const f32x4 (&ar)[AI], const f32x4 (&br)[BI], int buf, int r) {
-        if (r < AI) *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * r) * LDK + lcol * 4]) = ar[r];
-        else *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * (r - AI)) * LDK + lcol * 4]) = br[r - AI];
-    };
-    auto chunk = [&](int t, int buf, f32x4 (&lda)[AI], f32x4 (&ldb)[BI], const f32x4 (&sta)[AI],
-                     const f32x4 (&stb)[BI]) {
-        // (dev ablation flags in V: 1 no A traffic, 2 no LDS writes, 4 no LDS reads, 8 no barrier,
-        //  16 A from one line, 32 B from one line)
-        // k-step 0 (+ the A gathers of chunk t+2)
-        if (!(V & 4)) read_frags(fa1, fb1, buf, 1);
+
+    // One chunk of the K loop.  `ld*`: register set receiving chunk t+2; `st*`: set holding chunk t+1.
+    // Side operations are spread behind individual MFMAs and never conditional.
+    auto chunk = [&](int buf, f32x4 (&lda)[AI], f32x4 (&ldb)[BI], const f32x4 (&sta)[AI], const f32x4 (&stb)[BI]) {
+        // k-slot 0 (+ the A gathers of chunk t+2)
+        read_frags(fa1, fb1, buf, 1);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             mf(fa0, fb0, q);
-            if (q % (Q / AI) == 1) load_a(lda, q / (Q / AI));
+#pragma unroll
+            for (int i = 0; i < AI; ++i)
+                if ((i * Q) / AI == q) load_a(lda, i);
         }
-        // k-step 1 (+ the weight rows of chunk t+2)
-        if (!(V & 4)) read_frags(fa0, fb0, buf, 2);
+        // k-slot 1 (+ the weight rows of chunk t+2)
+        read_frags(fa0, fb0, buf, 2);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             mf(fa1, fb1, q);
-            if (q % (Q / BI) == 1) load_b(ldb, q / (Q / BI));
-            if (q == Q - 2) advance_k();
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                if ((i * Q) / BI == q) load_b(ldb, i);
+            if (q == Q - 1) advance_k();
         }
-        // k-step 2 (+ chunk t+1 goes to the other LDS buffer, one row per MFMA)
-        if (!(V & 4)) read_frags(fa1, fb1, buf, 3);
+        // k-slot 2 (+ chunk t+1 goes to the other LDS buffer)
+        read_frags(fa1, fb1, buf, 3);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             mf(fa0, fb0, q);
-            if (q < AI + BI && !(V & 2)) store_row(sta, stb, buf ^ 1, q);
+#pragma unroll
+            for (int r = 0; r < AI + BI; ++r)
+                if ((r * Q) / (AI + BI) == q) store_row(sta, stb, buf ^ 1, r);
         }
-        if (!(V & 8)) __syncthreads();
-        if (!(V & 4)) read_frags(fa0, fb0, buf ^ 1, 0);
-        // k-step 3
+        __syncthreads();
+        read_frags(fa0, fb0, buf ^ 1, 0);
+        // k-slot 3
 #pragma unroll
         for (int q = 0; q < Q; ++q) mf(fa1, fb1, q);
     };
 
     load_chunk(areg0, breg0);                       // chunk 0
-    store_chunk(areg0, breg0, 0);
-    load_chunk(areg1, breg1);                       // chunk 1 stays in registers until chunk 0's k-step 2
+#pragma unroll
+    for (int r = 0; r < AI + BI; ++r) store_row(areg0, breg0, 0, r);
+    load_chunk(areg1, breg1);                       // chunk 1 stays in registers until chunk 0's k-slot 2
     __syncthreads();
     read_frags(fa0, fb0, 0, 0);
-    if (V & 4) read_frags(fa1, fb1, 0, 1);
 
     for (int t = 0; t < nk; t += 2) {
-        chunk(t, 0, areg0, breg0, areg1, breg1);
-        if (t + 1 < nk) chunk(t + 1, 1, areg1, breg1, areg0, breg0);
+        chunk(0, areg0, breg0, areg1, breg1);
+        if (t + 1 < nk) chunk(1, areg1, breg1, areg0, breg0);
     }
 
     // ---- epilogue: y = act(acc*scale + shift + residual) --------------------------------------
@@ -268,11 +270,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
     // Branch-free: residual loads / stores are raw buffer ops rebased at this tile's first row;
     // rows >= M or cols >= K get an out-of-range offset (loads return 0, stores are dropped), so all
     // residual loads of a wave are in flight together instead of one vmcnt(0) per element.
+    const int YS = (F16 && !p.y_f32) ? 2 : 4;       // output element size
     const size_t tile_off = (size_t)m0 * p.K;
-    const unsigned y_bytes = (unsigned)min((size_t)BM, (size_t)(p.M - m0)) * (unsigned)p.K * 4u;
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + tile_off), 0, (int)y_bytes, 0x00020000);
+    const unsigned rows_here = (unsigned)min(BM, p.M - m0);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)p.y + tile_off * YS), 0, (int)(rows_here * (unsigned)p.K * YS), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((p.res ? p.res : p.y) + tile_off), 0, (int)y_bytes, 0x00020000);
+        (void*)((const char*)(p.res ? p.res : p.y) + tile_off * ES), 0, (int)(rows_here * (unsigned)p.K * ES), 0x00020000);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wn0 + j * 32 + (lane & 31);
@@ -281,53 +285,71 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvArgs p) {
         const float sh = (p.shift && nok) ? p.shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            unsigned off[16];
+            unsigned eo[16];      // element offset inside the tile
             float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                off[r] = nok ? (unsigned)(row * p.K + n) * 4u : kOob;      // rows >= M fall outside y_bytes
+                eo[r] = (unsigned)(row * p.K + n);
             }
             if (p.res) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off[r], 0, 0));
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (F16) {
+                        const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(r_rsrc, nok ? eo[r] * 2u : kOob, 0, 0);
+                        rv[r] = (float)__builtin_bit_cast(_Float16, h);
+                    } else {
+                        rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, nok ? eo[r] * 4u : kOob, 0, 0));
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r] * sc + sh;
                 if (p.res) v += rv[r];
                 if (p.relu) v = fmaxf(v, 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, off[r], 0, 0);
+                if constexpr (F16) {
+                    if (p.y_f32) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, nok ? eo[r] * 4u : kOob, 0, 0);
+                    } else {
+                        const _Float16 hv = (_Float16)v;
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), y_rsrc,
+                                                              nok ? eo[r] * 2u : kOob, 0, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, nok ? eo[r] * 4u : kOob, 0, 0);
+                }
             }
         }
     }
 }
 
-// OIHW [K,Cin,R,S] -> tile-contiguous packed weights [rows/BN][kred/32][BN][32] (zero fill).
-// Chunk q of the reduction covers, for Cstore >= 32: tap row r = q / (S*Cstore/32), channel chunk
-// cc = (q / S) % (Cstore/32), tap column s = q % S, channels cc*32 .. cc*32+31;
-// for Cstore < 32 (stem): reduction index kk = q*32 + col in plain (r, s, c) order.
-__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int K, int Cin,
-                                   int R, int S, int Cstore, int kred, int rows, int bn, int mode) {
+// OIHW fp32 [K,Cin,R,S] -> tile-contiguous packed weights of type T: [rows/BN][kred/BKE][BN][BKE].
+// Chunk q of the reduction covers, for Cstore >= BKE: tap row r = q / (S*Cstore/BKE), channel chunk
+// cc = (q / S) % (Cstore/BKE), tap column s = q % S, channels cc*BKE ..; for Cstore < BKE (stem):
+// reduction index kk = q*BKE + col in plain (r, s, c) order.
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Cin, int R, int S,
+                                   int Cstore, int kred, int rows, int bn, int mode) {
+    constexpr int BKE = CHUNK_BYTES / (int)sizeof(T);
     const size_t total = (size_t)rows * kred;
-    const int nk = kred / BK;
+    const int nk = kred / BKE;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % BK);
-        size_t rest = i / BK;
+        const int col = (int)(i % BKE);
+        size_t rest = i / BKE;
         const int row_in = (int)(rest % bn);
         rest /= bn;
         const int q = (int)(rest % nk);
         const int tn = (int)(rest / nk);
         const int row = tn * bn + row_in;
         int r, s2, c;
-        if (Cstore >= BK) {
-            const int ccn = Cstore / BK;
+        if (Cstore >= BKE) {
+            const int ccn = Cstore / BKE;
             s2 = q % S;
-            c = ((q / S) % ccn) * BK + col;
+            c = ((q / S) % ccn) * BKE + col;
             r = q / (S * ccn);
         } else {
-            const int kk = q * BK + col;
+            const int kk = q * BKE + col;
             const int pos = kk / Cstore;
             c = kk - pos * Cstore;
             r = pos / S;
@@ -344,63 +366,86 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
                 v = w[(((size_t)c * cout + co) * 2 + (ab >> 1)) * 2 + (ab & 1)];
             }
         }
-        out[i] = v;
+        out[i] = (T)v;
     }
 }
 
-}  // namespace
+template <typename T>
+int kred_of(int C, int R, int S) {
+    constexpr int BKE = CHUNK_BYTES / (int)sizeof(T);
+    return ((R * S * C + BKE - 1) / BKE) * BKE;
+}
 
-extern "C" {
-
-int seam_conv_kred(int C, int R, int S) { return ((R * S * C + BK - 1) / BK) * BK; }
-int seam_conv_rows_padded(int K) { return ((K + 63) / 64) * 64; }
-
-int seam_pack_conv_weight_f32(const float* w, float* w_packed, int K, int Cin, int R, int S, int Cstore,
-                              int mode, void* stream) {
-    const int kred = seam_conv_kred(Cstore, R, S);
-    const int rows = seam_conv_rows_padded(K);
+template <typename T>
+int pack_weight(const float* w, void* w_packed, int K, int Cin, int R, int S, int Cstore, int mode, void* stream) {
+    constexpr int BKE = CHUNK_BYTES / (int)sizeof(T), EPV = 16 / (int)sizeof(T);
+    if ((Cstore % EPV) || (Cstore >= BKE && Cstore % BKE)) return (int)hipErrorInvalidValue;
+    const int kred = kred_of<T>(Cstore, R, S);
+    const int rows = ((K + 63) / 64) * 64;
     const size_t total = (size_t)rows * kred;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    if (Cstore >= BK && Cstore % BK) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_packed, K, Cin, R,
-                       S, Cstore, kred, rows, rows % 128 == 0 ? 128 : 64, mode);
+    hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (T*)w_packed, K, Cin, R, S,
+                       Cstore, kred, rows, rows % 128 == 0 ? 128 : 64, mode);
     return (int)hipGetLastError();
 }
 
-int seam_conv2d_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
-                    const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S, int stride,
-                    int pad, int relu, void* stream) {
-    if ((C & 3) || (C >= BK && C % BK) || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+template <typename T>
+int conv2d(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
+           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, int y_f32, void* stream) {
+    constexpr int BKE = CHUNK_BYTES / (int)sizeof(T), EPV = 16 / (int)sizeof(T);
+    if ((C % EPV) || (C >= BKE && C % BKE) || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.N = N; a.H = H; a.W = W; a.C = C;
     a.Ho = (H + 2 * pad - R) / stride + 1;
     a.Wo = (W + 2 * pad - S) / stride + 1;
     a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
-    a.kred = seam_conv_kred(C, R, S);
+    a.kred = kred_of<T>(C, R, S);
     a.M = N * a.Ho * a.Wo;
     a.relu = relu;
+    a.y_f32 = y_f32;
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
-    const int rows = seam_conv_rows_padded(K);
-    static const int variant = getenv("SEAM_CONV_VARIANT") ? atoi(getenv("SEAM_CONV_VARIANT")) : 0;   // dev knob
+    const int rows = ((K + 63) / 64) * 64;
+    a.tiles_m = (a.M + 127) / 128;
     if (rows % 128 == 0) {
-        a.tiles_m = (a.M + 127) / 128;
         a.tiles_n = rows / 128;
-        const dim3 g(a.tiles_m * a.tiles_n), b(256);
-        if (variant == 1) hipLaunchKernelGGL((conv_igemm_f32<128, 128, 1>), g, b, 0, (hipStream_t)stream, a);
-        else if (variant == 16) hipLaunchKernelGGL((conv_igemm_f32<128, 128, 16>), g, b, 0, (hipStream_t)stream, a);
-        else if (variant == 32) hipLaunchKernelGGL((conv_igemm_f32<128, 128, 32>), g, b, 0, (hipStream_t)stream, a);
-        else if (variant == 48) hipLaunchKernelGGL((conv_igemm_f32<128, 128, 48>), g, b, 0, (hipStream_t)stream, a);
-        else if (variant == 17) hipLaunchKernelGGL((conv_igemm_f32<128, 128, 17>), g, b, 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((conv_igemm_f32<128, 128>), g, b, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_igemm<T, 128, 128>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
     } else {
-        a.tiles_m = (a.M + 127) / 128;
         a.tiles_n = rows / 64;
-        hipLaunchKernelGGL((conv_igemm_f32<128, 64>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0,
-                           (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_igemm<T, 128, 64>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
     }
     return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int seam_conv_kred(int C, int R, int S) { return kred_of<float>(C, R, S); }
+int seam_conv_kred_f16(int C, int R, int S) { return kred_of<_Float16>(C, R, S); }
+int seam_conv_rows_padded(int K) { return ((K + 63) / 64) * 64; }
+
+int seam_pack_conv_weight_f32(const float* w, float* w_packed, int K, int Cin, int R, int S, int Cstore, int mode,
+                              void* stream) {
+    return pack_weight<float>(w, w_packed, K, Cin, R, S, Cstore, mode, stream);
+}
+
+int seam_pack_conv_weight_f16(const float* w, void* w_packed, int K, int Cin, int R, int S, int Cstore, int mode,
+                              void* stream) {
+    return pack_weight<_Float16>(w, w_packed, K, Cin, R, S, Cstore, mode, stream);
+}
+
+int seam_conv2d_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                    const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S, int stride,
+                    int pad, int relu, void* stream) {
+    return conv2d<float>(x, w_packed, scale, shift, residual, y, N, H, W, C, K, R, S, stride, pad, relu, 1, stream);
+}
+
+int seam_conv2d_f16(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual,
+                    void* y, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu,
+                    int y_f32, void* stream) {
+    return conv2d<_Float16>(x, w_packed, scale, shift, residual, y, N, H, W, C, K, R, S, stride, pad, relu, y_f32, stream);
 }
 
 }  // extern "C"

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict
 }
 
 // logits [K,14,14,4,ncls] (sub-pixel (a,b) groups) -> prob [K,1,28,28], channel labels[k]
-__global__ void mask_select_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+template <typename T>
+__global__ void mask_select_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                    float* __restrict__ prob, int K, int ncls) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K * 784) return;
@@ -108,7 +109,7 @@ __global__ void mask_select_kernel(const float* __restrict__ logits, const int64
     const int y = r / 28, x = r - y * 28;
     const int h = y >> 1, a = y & 1, w = x >> 1, b = x & 1;
     const int lab = (int)labels[k];
-    const float v = logits[((((size_t)k * 14 + h) * 14 + w) * 4 + (a * 2 + b)) * ncls + lab];
+    const float v = (float)logits[((((size_t)k * 14 + h) * 14 + w) * 4 + (a * 2 + b)) * ncls + lab];
     prob[i] = 1.f / (1.f + expf(-v));
 }
 
@@ -181,8 +182,16 @@ int seam_paste_masks_f32(const float* masks, const float* boxes, float* out, int
 int seam_mask_select_f32(const float* logits, const int64_t* labels, float* prob, int K, int ncls, void* stream) {
     if (K <= 0) return 0;
     const int total = K * 784;
-    hipLaunchKernelGGL(mask_select_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits,
+    hipLaunchKernelGGL(mask_select_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits,
                        labels, prob, K, ncls);
+    return (int)hipGetLastError();
+}
+
+int seam_mask_select_f16(const void* logits, const int64_t* labels, float* prob, int K, int ncls, void* stream) {
+    if (K <= 0) return 0;
+    const int total = K * 784;
+    hipLaunchKernelGGL(mask_select_kernel<_Float16>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)logits, labels, prob, K, ncls);
     return (int)hipGetLastError();
 }
 

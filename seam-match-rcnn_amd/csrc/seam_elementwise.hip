@@ -1,5 +1,5 @@
-// seam_elementwise.hip -- HBM-bound glue kernels of the path (NHWC fp32, 16 B per lane).
-//   preprocess   GeneralizedRCNNTransform: normalise + bilinear resize + pad + CHW->NHWC4
+// seam_elementwise.hip -- HBM-bound glue kernels of the path (NHWC, 16 B per lane), fp32 and fp16:
+//   preprocess   GeneralizedRCNNTransform: normalise + bilinear resize + pad + CHW->NHWC (4 / 8 stored ch.)
 //   maxpool2d    ResNet stem pool / FPN LastLevelMaxPool
 //   upsample_add FPN top-down merge (nearest)
 //   transposes   NCHW <-> NHWC bridges at the module boundary (LDS-tiled, both sides coalesced)
@@ -10,6 +10,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+template <typename T> struct Vec16;                       // 16 bytes of T
+template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+template <> struct Vec16<_Float16> { typedef _Float16 type __attribute__((ext_vector_type(8))); static constexpr int N = 8; };
 
 __device__ __forceinline__ void bilinear_axis(int dst, int in, int out, int& i0, int& i1, float& l1) {
     // ATen upsample_bilinear2d, align_corners=False, scale = in/out (recompute_scale_factor=True)
@@ -24,12 +28,14 @@ __device__ __forceinline__ void bilinear_axis(int dst, int in, int out, int& i0,
     l1 = fminf(fmaxf(l, 0.f), 1.f);
 }
 
-__global__ void preprocess_kernel(const float* __restrict__ img, float* __restrict__ out, int in_h, int in_w,
+template <typename T>
+__global__ void preprocess_kernel(const float* __restrict__ img, T* __restrict__ out, int in_h, int in_w,
                                   int out_h, int out_w, int Hp, int Wp) {
+    typedef typename Vec16<T>::type V;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= Wp) return;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    float v[3] = {0.f, 0.f, 0.f};
     if (y < out_h && x < out_w) {
         const float mean[3] = {0.485f, 0.456f, 0.406f};
         const float stdv[3] = {0.229f, 0.224f, 0.225f};
@@ -53,44 +59,58 @@ __global__ void preprocess_kernel(const float* __restrict__ img, float* __restri
             }
         }
     }
-    *reinterpret_cast<f32x4*>(out + ((size_t)y * Wp + x) * 4) = v;
+    V o;
+#pragma unroll
+    for (int c = 0; c < Vec16<T>::N; ++c) o[c] = (T)(c < 3 ? v[c] : 0.f);
+    *reinterpret_cast<V*>(out + ((size_t)y * Wp + x) * Vec16<T>::N) = o;
 }
 
-__global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
                                int Ho, int Wo, int k, int stride, int pad) {
-    const int c4 = C >> 2;
-    const size_t total = (size_t)N * Ho * Wo * c4;
+    typedef typename Vec16<T>::type V;
+    constexpr int E = Vec16<T>::N;
+    const int cv = C / E;
+    const size_t total = (size_t)N * Ho * Wo * cv;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4);
-        size_t r = i / c4;
+        const int c = (int)(i % cv);
+        size_t r = i / cv;
         const int wo = (int)(r % Wo);
         r /= Wo;
         const int ho = (int)(r % Ho);
         const int n = (int)(r / Ho);
-        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        float m[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) m[e] = -INFINITY;
         for (int a = 0; a < k; ++a) {
             const int hi = ho * stride - pad + a;
             if ((unsigned)hi >= (unsigned)H) continue;
             for (int b = 0; b < k; ++b) {
                 const int wi = wo * stride - pad + b;
                 if ((unsigned)wi >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + hi) * W + wi) * C + c * 4);
-                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]);
-                m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+                const V v = *reinterpret_cast<const V*>(x + (((size_t)n * H + hi) * W + wi) * C + c * E);
+#pragma unroll
+                for (int e = 0; e < E; ++e) m[e] = fmaxf(m[e], (float)v[e]);
             }
         }
-        *reinterpret_cast<f32x4*>(y + i * 4) = m;
+        V o;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = (T)m[e];
+        *reinterpret_cast<V*>(y + i * E) = o;
     }
 }
 
-__global__ void upsample_add_kernel(float* __restrict__ lat, const float* __restrict__ top, int N, int H, int W,
+template <typename T>
+__global__ void upsample_add_kernel(T* __restrict__ lat, const T* __restrict__ top, int N, int H, int W,
                                     int Ht, int Wt, int C) {
-    const int c4 = C >> 2;
-    const size_t total = (size_t)N * H * W * c4;
+    typedef typename Vec16<T>::type V;
+    constexpr int E = Vec16<T>::N;
+    const int cv = C / E;
+    const size_t total = (size_t)N * H * W * cv;
     const float sh = (float)Ht / (float)H, sw = (float)Wt / (float)W;   // ATen nearest: floor(dst*scale)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4);
-        size_t r = i / c4;
+        const int c = (int)(i % cv);
+        size_t r = i / cv;
         const int w = (int)(r % W);
         r /= W;
         const int h = (int)(r % H);
@@ -99,15 +119,17 @@ __global__ void upsample_add_kernel(float* __restrict__ lat, const float* __rest
         int wt = (int)floorf((float)w * sw);
         if (ht > Ht - 1) ht = Ht - 1;
         if (wt > Wt - 1) wt = Wt - 1;
-        f32x4 a = *reinterpret_cast<f32x4*>(lat + i * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(top + (((size_t)n * Ht + ht) * Wt + wt) * C + c * 4);
-        a += b;
-        *reinterpret_cast<f32x4*>(lat + i * 4) = a;
+        V a = *reinterpret_cast<V*>(lat + i * E);
+        const V b = *reinterpret_cast<const V*>(top + (((size_t)n * Ht + ht) * Wt + wt) * C + c * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e] = (T)((float)a[e] + (float)b[e]);
+        *reinterpret_cast<V*>(lat + i * E) = a;
     }
 }
 
 // y[b][j][i] = x[b][i][j]; x is [B][rows][cols]
-__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+template <typename TI, typename TO>
+__global__ void transpose_kernel(const TI* __restrict__ x, TO* __restrict__ y, int rows, int cols) {
     __shared__ float tile[32][33];
     const size_t boff = (size_t)blockIdx.z * rows * cols;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -115,25 +137,26 @@ __global__ void transpose_kernel(const float* __restrict__ x, float* __restrict_
 #pragma unroll
     for (int k = 0; k < 32; k += 8) {
         const int r = r0 + ty + k, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + k][tx] = x[boff + (size_t)r * cols + c];
+        if (r < rows && c < cols) tile[ty + k][tx] = (float)x[boff + (size_t)r * cols + c];
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 32; k += 8) {
         const int c = c0 + ty + k, r = r0 + tx;
-        if (r < rows && c < cols) y[boff + (size_t)c * rows + r] = tile[tx][ty + k];
+        if (r < rows && c < cols) y[boff + (size_t)c * rows + r] = (TO)tile[tx][ty + k];
     }
 }
 
-__global__ void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int K, int L, int C) {
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int K, int L, int C) {
     const size_t total = (size_t)K * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const size_t k = i / C;
-        const float* p = x + k * L * C + c;
+        const T* p = x + k * L * C + c;
         float s = 0.f;
-        for (int l = 0; l < L; ++l) s += p[(size_t)l * C];
-        y[i] = s / (float)L;
+        for (int l = 0; l < L; ++l) s += (float)p[(size_t)l * C];
+        y[i] = (T)(s / (float)L);
     }
 }
 
@@ -144,54 +167,88 @@ inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
     return (int)g;
 }
 
-}  // namespace
-
-extern "C" {
-
-int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp,
-                        void* stream) {
+template <typename T>
+int preprocess(const float* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, void* stream) {
     dim3 grid((Wp + 255) / 256, Hp);
-    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, out, in_h, in_w, out_h,
+    hipLaunchKernelGGL(preprocess_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, img, (T*)out, in_h, in_w, out_h,
                        out_w, Hp, Wp);
     return (int)hipGetLastError();
 }
 
-int seam_maxpool2d_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad,
-                       void* stream) {
-    if (C & 3) return (int)hipErrorInvalidValue;
+template <typename T>
+int maxpool(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad, void* stream) {
+    if (C % Vec16<T>::N) return (int)hipErrorInvalidValue;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
-    const size_t total = (size_t)N * Ho * Wo * (C >> 2);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C,
-                       Ho, Wo, k, stride, pad);
+    const size_t total = (size_t)N * Ho * Wo * (C / Vec16<T>::N);
+    hipLaunchKernelGGL(maxpool_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, N,
+                       H, W, C, Ho, Wo, k, stride, pad);
     return (int)hipGetLastError();
 }
 
-int seam_upsample_add_f32(float* lat, const float* top, int N, int H, int W, int Ht, int Wt, int C, void* stream) {
-    if (C & 3) return (int)hipErrorInvalidValue;
-    const size_t total = (size_t)N * H * W * (C >> 2);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, lat, top, N,
-                       H, W, Ht, Wt, C);
+template <typename T>
+int upsample_add(void* lat, const void* top, int N, int H, int W, int Ht, int Wt, int C, void* stream) {
+    if (C % Vec16<T>::N) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)N * H * W * (C / Vec16<T>::N);
+    hipLaunchKernelGGL(upsample_add_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (T*)lat,
+                       (const T*)top, N, H, W, Ht, Wt, C);
     return (int)hipGetLastError();
+}
+
+template <typename TI, typename TO>
+int transpose(const void* x, void* y, int B, int rows, int cols, void* stream) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, B);
+    hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, dim3(256), 0, (hipStream_t)stream, (const TI*)x, (TO*)y, rows, cols);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int avgpool(const void* x, void* y, int K, int L, int C, void* stream) {
+    hipLaunchKernelGGL(avgpool_kernel<T>, dim3(grid_for((size_t)K * C)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                       (T*)y, K, L, C);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, void* stream) {
+    return preprocess<float>(img, out, in_h, in_w, out_h, out_w, Hp, Wp, stream);
+}
+int seam_preprocess_f16(const float* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, void* stream) {
+    return preprocess<_Float16>(img, out, in_h, in_w, out_h, out_w, Hp, Wp, stream);
+}
+
+int seam_maxpool2d_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad, void* stream) {
+    return maxpool<float>(x, y, N, H, W, C, k, stride, pad, stream);
+}
+int seam_maxpool2d_f16(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad, void* stream) {
+    return maxpool<_Float16>(x, y, N, H, W, C, k, stride, pad, stream);
+}
+
+int seam_upsample_add_f32(float* lat, const float* top, int N, int H, int W, int Ht, int Wt, int C, void* stream) {
+    return upsample_add<float>(lat, top, N, H, W, Ht, Wt, C, stream);
+}
+int seam_upsample_add_f16(void* lat, const void* top, int N, int H, int W, int Ht, int Wt, int C, void* stream) {
+    return upsample_add<_Float16>(lat, top, N, H, W, Ht, Wt, C, stream);
 }
 
 // x [B,C,L] -> y [B,L,C]
 int seam_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int L, void* stream) {
-    dim3 grid((L + 31) / 32, (C + 31) / 32, B);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, L);
-    return (int)hipGetLastError();
+    return transpose<float, float>(x, y, B, C, L, stream);
 }
-
+int seam_nchw_f32_to_nhwc_f16(const float* x, void* y, int B, int C, int L, void* stream) {
+    return transpose<float, _Float16>(x, y, B, C, L, stream);
+}
 // x [B,L,C] -> y [B,C,L]
 int seam_nhwc_to_nchw_f32(const float* x, float* y, int B, int L, int C, void* stream) {
-    dim3 grid((C + 31) / 32, (L + 31) / 32, B);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, L, C);
-    return (int)hipGetLastError();
+    return transpose<float, float>(x, y, B, L, C, stream);
+}
+int seam_nhwc_f16_to_nchw_f32(const void* x, float* y, int B, int L, int C, void* stream) {
+    return transpose<_Float16, float>(x, y, B, L, C, stream);
 }
 
-int seam_avgpool_f32(const float* x, float* y, int K, int L, int C, void* stream) {
-    hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for((size_t)K * C)), dim3(256), 0, (hipStream_t)stream, x, y, K,
-                       L, C);
-    return (int)hipGetLastError();
-}
+int seam_avgpool_f32(const float* x, float* y, int K, int L, int C, void* stream) { return avgpool<float>(x, y, K, L, C, stream); }
+int seam_avgpool_f16(const void* x, void* y, int K, int L, int C, void* stream) { return avgpool<_Float16>(x, y, K, L, C, stream); }
 
 }  // extern "C"

@@ -12,13 +12,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 struct RoiArgs {
-    const float* feat[4];
+    const void* feat[4];
     int h[4], w[4];
     float scale[4];
     int C, k_min;
     const float* rois;
     const int* levels;
-    float* out;
+    void* out;
     int K, P, sr;
 };
 
@@ -30,7 +30,9 @@ __device__ __forceinline__ int map_level(float x1, float y1, float x2, float y2,
     return (int)l - k_min;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
+    typedef T tv4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per bin
     const int PP = p.P * p.P;
@@ -47,8 +49,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
     const int H = lvl == 0 ? p.h[0] : lvl == 1 ? p.h[1] : lvl == 2 ? p.h[2] : p.h[3];
     const int W = lvl == 0 ? p.w[0] : lvl == 1 ? p.w[1] : lvl == 2 ? p.w[2] : p.w[3];
     const float sc = lvl == 0 ? p.scale[0] : lvl == 1 ? p.scale[1] : lvl == 2 ? p.scale[2] : p.scale[3];
-    const float* fb = lvl == 0 ? p.feat[0] : lvl == 1 ? p.feat[1] : lvl == 2 ? p.feat[2] : p.feat[3];
-    const float* f = fb + (size_t)bidx * H * W * p.C;
+    const T* fb = (const T*)(lvl == 0 ? p.feat[0] : lvl == 1 ? p.feat[1] : lvl == 2 ? p.feat[2] : p.feat[3]);
+    const T* f = fb + (size_t)bidx * H * W * p.C;
 
     const float x1 = bx1 * sc, y1 = by1 * sc, x2 = bx2 * sc, y2 = by2 * sc;
     const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
@@ -71,24 +73,26 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
                 const float ly = yy - (float)yl, lx = x - (float)xl;
                 const float hy = 1.f - ly, hx = 1.f - lx;
                 const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(f + ((size_t)yl * W + xl) * p.C + c0);
-                const f32x4 v2 = *reinterpret_cast<const f32x4*>(f + ((size_t)yl * W + xh) * p.C + c0);
-                const f32x4 v3 = *reinterpret_cast<const f32x4*>(f + ((size_t)yh * W + xl) * p.C + c0);
-                const f32x4 v4 = *reinterpret_cast<const f32x4*>(f + ((size_t)yh * W + xh) * p.C + c0);
+                const tv4 t1 = *reinterpret_cast<const tv4*>(f + ((size_t)yl * W + xl) * p.C + c0);
+                const tv4 t2 = *reinterpret_cast<const tv4*>(f + ((size_t)yl * W + xh) * p.C + c0);
+                const tv4 t3 = *reinterpret_cast<const tv4*>(f + ((size_t)yh * W + xl) * p.C + c0);
+                const tv4 t4 = *reinterpret_cast<const tv4*>(f + ((size_t)yh * W + xh) * p.C + c0);
+                const f32x4 v1 = __builtin_convertvector(t1, f32x4), v2 = __builtin_convertvector(t2, f32x4);
+                const f32x4 v3 = __builtin_convertvector(t3, f32x4), v4 = __builtin_convertvector(t4, f32x4);
                 acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
             }
         }
         acc /= cnt;
-        *reinterpret_cast<f32x4*>(p.out + (size_t)bin * p.C + c0) = acc;
+        *reinterpret_cast<tv4*>((T*)p.out + (size_t)bin * p.C + c0) = __builtin_convertvector(acc, tv4);
     }
 }
 
 }  // namespace
 
-extern "C" int seam_roi_align_f32(const float* feat0, const float* feat1, const float* feat2, const float* feat3,
-                                  const int* hw, int C, float scale0, float scale1, float scale2, float scale3,
-                                  int k_min, const float* rois, const int* levels, float* out, int K, int P,
-                                  int sampling_ratio, void* stream) {
+template <typename T>
+static int roi_align_launch(const void* feat0, const void* feat1, const void* feat2, const void* feat3, const int* hw, int C,
+                            float scale0, float scale1, float scale2, float scale3, int k_min, const float* rois,
+                            const int* levels, void* out, int K, int P, int sampling_ratio, void* stream) {
     if (K <= 0) return 0;
     if ((C & 3) || C > 1024 * 4) return (int)hipErrorInvalidValue;
     RoiArgs a;
@@ -98,6 +102,22 @@ extern "C" int seam_roi_align_f32(const float* feat0, const float* feat1, const 
     a.C = C; a.k_min = k_min; a.rois = rois; a.levels = levels; a.out = out; a.K = K; a.P = P;
     a.sr = sampling_ratio;
     const long bins = (long)K * P * P;
-    hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)((bins + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(roi_align_kernel<T>, dim3((unsigned)((bins + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
+}
+
+extern "C" int seam_roi_align_f32(const float* feat0, const float* feat1, const float* feat2, const float* feat3,
+                                  const int* hw, int C, float scale0, float scale1, float scale2, float scale3,
+                                  int k_min, const float* rois, const int* levels, float* out, int K, int P,
+                                  int sampling_ratio, void* stream) {
+    return roi_align_launch<float>(feat0, feat1, feat2, feat3, hw, C, scale0, scale1, scale2, scale3, k_min, rois, levels,
+                                   out, K, P, sampling_ratio, stream);
+}
+
+extern "C" int seam_roi_align_f16(const void* feat0, const void* feat1, const void* feat2, const void* feat3,
+                                  const int* hw, int C, float scale0, float scale1, float scale2, float scale3,
+                                  int k_min, const float* rois, const int* levels, void* out, int K, int P,
+                                  int sampling_ratio, void* stream) {
+    return roi_align_launch<_Float16>(feat0, feat1, feat2, feat3, hw, C, scale0, scale1, scale2, scale3, k_min, rois,
+                                      levels, out, K, P, sampling_ratio, stream);
 }

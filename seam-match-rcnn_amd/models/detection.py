@@ -31,8 +31,22 @@ RESNET50_LAYERS = ((3, 64, 1), (4, 128, 2), (6, 256, 2), (3, 512, 2))
 BBOX_XFORM_CLIP = math.log(1000.0 / 16)
 
 
-def _key(params) -> tuple:
-    return tuple((p.data_ptr(), p._version) for p in params)
+def _key(params, dtype=None) -> tuple:
+    return tuple((p.data_ptr(), p._version) for p in params) + (dtype,)
+
+
+def cdt(module) -> torch.dtype:
+    """Compute precision of a module: torch.float32 (exact, default) or torch.float16 (the fp16-MFMA /
+    fp32-accumulate path of BASELINE config 5).  Set for a whole model with ``set_compute_dtype``."""
+    return getattr(module, "compute_dtype", torch.float32)
+
+
+def set_compute_dtype(model: nn.Module, dtype: torch.dtype) -> nn.Module:
+    if dtype not in (torch.float32, torch.float16):
+        raise ValueError("compute dtype must be torch.float32 or torch.float16")
+    for m in model.modules():
+        m.compute_dtype = dtype
+    return model
 
 
 # ------------------------------------------------------------------------------ transform (a2)
@@ -49,13 +63,14 @@ class GeneralizedRCNNTransform(nn.Module):
         self.min_size, self.max_size, self.size_divisible = min_size, max_size, size_divisible
 
     def forward(self, images: Sequence[torch.Tensor]):
-        """list of [3,H,W] in [0,1] -> (NHWC4 batch [N,Hp,Wp,4], image_sizes, original_sizes)."""
+        """list of [3,H,W] in [0,1] -> (NHWC batch [N,Hp,Wp,4] fp32 | [N,Hp,Wp,8] fp16, image_sizes,
+        original_sizes)."""
         orig = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]
         sizes = [resized_size(h, w, self.min_size, self.max_size)[:2] for h, w in orig]
         d = self.size_divisible
         hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
         wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
-        return ops.preprocess(images, sizes, hp, wp), sizes, orig
+        return ops.preprocess(images, sizes, hp, wp, cdt(self)), sizes, orig
 
     @staticmethod
     def rescale_boxes(boxes: torch.Tensor, from_hw, to_hw) -> torch.Tensor:
@@ -117,20 +132,21 @@ class ResNet50Body(nn.Module):
         return list(self.parameters()) + list(self.buffers())
 
     def packed(self):
-        key = _key(self._all())
+        dt = cdt(self)
+        key = _key(self._all(), dt)
         if self._pk is None or key != self._pk_key:
             with torch.no_grad():
-                pk = {"stem": ops.pack_conv(self.conv1.weight, None, self.bn1.tensors(), stride=2, pad=3, cstore=4,
-                                            bn_eps=self.bn1.eps)}
+                pk = {"stem": ops.pack_conv(self.conv1.weight, None, self.bn1.tensors(), stride=2, pad=3,
+                                            cstore=4 if dt == torch.float32 else 8, bn_eps=self.bn1.eps, dtype=dt)}
                 for li in range(1, 5):
                     for bi, b in enumerate(getattr(self, f"layer{li}")):
-                        e = {"c1": ops.pack_conv(b.conv1.weight, None, b.bn1.tensors(), bn_eps=b.bn1.eps),
+                        e = {"c1": ops.pack_conv(b.conv1.weight, None, b.bn1.tensors(), bn_eps=b.bn1.eps, dtype=dt),
                              "c2": ops.pack_conv(b.conv2.weight, None, b.bn2.tensors(), stride=b.stride, pad=1,
-                                                 bn_eps=b.bn2.eps),
-                             "c3": ops.pack_conv(b.conv3.weight, None, b.bn3.tensors(), bn_eps=b.bn3.eps)}
+                                                 bn_eps=b.bn2.eps, dtype=dt),
+                             "c3": ops.pack_conv(b.conv3.weight, None, b.bn3.tensors(), bn_eps=b.bn3.eps, dtype=dt)}
                         if b.downsample is not None:
                             e["ds"] = ops.pack_conv(b.downsample[0].weight, None, b.downsample[1].tensors(),
-                                                    stride=b.stride, bn_eps=b.downsample[1].eps)
+                                                    stride=b.stride, bn_eps=b.downsample[1].eps, dtype=dt)
                         pk[(li, bi)] = e
             self._pk, self._pk_key = pk, key
         return self._pk
@@ -168,11 +184,12 @@ class FeaturePyramidNetwork(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *a, **k)
 
     def packed(self):
-        key = _key(self.parameters())
+        dt = cdt(self)
+        key = _key(self.parameters(), dt)
         if self._pk is None or key != self._pk_key:
             with torch.no_grad():
-                self._pk = ([ops.pack_conv(m.weight, m.bias) for m in self.inner_blocks],
-                            [ops.pack_conv(m.weight, m.bias, pad=1) for m in self.layer_blocks])
+                self._pk = ([ops.pack_conv(m.weight, m.bias, dtype=dt) for m in self.inner_blocks],
+                            [ops.pack_conv(m.weight, m.bias, pad=1, dtype=dt) for m in self.layer_blocks])
             self._pk_key = key
         return self._pk
 
@@ -228,12 +245,13 @@ class RPNHead(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *a, **k)
 
     def packed(self):
-        key = _key(self.parameters())
+        dt = cdt(self)
+        key = _key(self.parameters(), dt)
         if self._pk is None or key != self._pk_key:
             with torch.no_grad():
                 w = torch.cat([self.cls_logits.weight, self.bbox_pred.weight], 0)       # A + 4A rows, one launch
                 b = torch.cat([self.cls_logits.bias, self.bbox_pred.bias], 0)
-                self._pk = (ops.pack_conv(self.conv.weight, self.conv.bias, pad=1), ops.pack_conv(w, b))
+                self._pk = (ops.pack_conv(self.conv.weight, self.conv.bias, pad=1, dtype=dt), ops.pack_conv(w, b, dtype=dt))
             self._pk_key = key
         return self._pk
 
@@ -244,7 +262,7 @@ class RPNHead(nn.Module):
         a = self.num_anchors
         out = []
         for f in feats:
-            o = ops.conv2d(ops.conv2d(f, conv, relu=True), heads)
+            o = ops.conv2d(ops.conv2d(f, conv, relu=True), heads, out_f32=True)     # logits/deltas leave in fp32
             out.append((o[..., :a], o[..., a:]))
         return out
 
@@ -387,12 +405,13 @@ class TwoMLPHead(nn.Module):
         self._pk, self._pk_key = None, None
 
     def packed(self):
-        key = _key(self.parameters())
+        dt = cdt(self)
+        key = _key(self.parameters(), dt)
         if self._pk is None or key != self._pk_key:
             with torch.no_grad():
                 # fc6 over flatten(C,7,7) == a 7x7 valid conv over the NHWC ROI tile
                 w6 = self.fc6.weight.view(self.fc6.out_features, 256, 7, 7)
-                self._pk = (ops.pack_conv(w6, self.fc6.bias), ops.pack_conv(self.fc7.weight, self.fc7.bias))
+                self._pk = (ops.pack_conv(w6, self.fc6.bias, dtype=dt), ops.pack_conv(self.fc7.weight, self.fc7.bias, dtype=dt))
             self._pk_key = key
         return self._pk
 
@@ -411,13 +430,14 @@ class FastRCNNPredictor(nn.Module):
         self._pk, self._pk_key = None, None
 
     def forward(self, x):
-        key = _key(self.parameters())
+        dt = cdt(self)
+        key = _key(self.parameters(), dt)
         if self._pk is None or key != self._pk_key:
             with torch.no_grad():
                 self._pk = ops.pack_conv(torch.cat([self.cls_score.weight, self.bbox_pred.weight], 0),
-                                         torch.cat([self.cls_score.bias, self.bbox_pred.bias], 0))
+                                         torch.cat([self.cls_score.bias, self.bbox_pred.bias], 0), dtype=dt)
             self._pk_key = key
-        o = ops.linear(x, self._pk)
+        o = ops.linear(x, self._pk, out_f32=True)
         return o[:, :self.num_classes], o[:, self.num_classes:]
 
 
@@ -442,11 +462,12 @@ class MaskRCNNHeads(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *a, **k)
 
     def forward(self, x):                        # NHWC [K,14,14,256]
-        key = _key(self.parameters())
+        dt = cdt(self)
+        key = _key(self.parameters(), dt)
         if self._pk is None or key != self._pk_key:
             with torch.no_grad():
-                self._pk = [ops.pack_conv(getattr(self, f"mask_fcn{i}").weight, getattr(self, f"mask_fcn{i}").bias, pad=1)
-                            for i in range(1, self.n + 1)]
+                self._pk = [ops.pack_conv(getattr(self, f"mask_fcn{i}").weight, getattr(self, f"mask_fcn{i}").bias, pad=1,
+                                          dtype=dt) for i in range(1, self.n + 1)]
             self._pk_key = key
         for pc in self._pk:
             x = ops.conv2d(x, pc, relu=True)
@@ -466,11 +487,12 @@ class MaskRCNNPredictor(nn.Module):
         """NHWC [K,14,14,256] -> logits [K,14,14,4*ncls]: the 2x2/s2 transposed conv is a 1x1 conv to
         4 sub-pixel channel groups (a,b); the 1x1 logits conv commutes with the depth-to-space, so
         it runs per group and ``seam_mask_select_f32`` reads the 28x28 map straight out of it."""
-        key = _key(self.parameters())
+        dt = cdt(self)
+        key = _key(self.parameters(), dt)
         if self._pk is None or key != self._pk_key:
             with torch.no_grad():
-                self._pk = (ops.pack_conv(self.conv5_mask.weight, self.conv5_mask.bias, transposed2x2=True),
-                            ops.pack_conv(self.mask_fcn_logits.weight, self.mask_fcn_logits.bias))
+                self._pk = (ops.pack_conv(self.conv5_mask.weight, self.conv5_mask.bias, transposed2x2=True, dtype=dt),
+                            ops.pack_conv(self.mask_fcn_logits.weight, self.mask_fcn_logits.bias, dtype=dt))
             self._pk_key = key
         up, logits = self._pk
         k = x.shape[0]

@@ -86,12 +86,13 @@ class MatchPredictor(nn.Module):
         bn = self.linear[1]
         ps = [self.conv_seq[i].weight for i in (0, 2, 4, 6)] + [self.conv_seq[i].bias for i in (0, 2, 4, 6)] + [
             self.linear[0].weight, self.linear[0].bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        dt = getattr(self, "compute_dtype", torch.float32)      # fp32 (exact) | fp16 MFMA trunk (config 5)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (dt,)
         if self._trunk_pk is None or key != self._trunk_key:
             with torch.no_grad():
-                convs = [ops.pack_conv(self.conv_seq[i].weight, self.conv_seq[i].bias) for i in (0, 2, 4, 6)]
+                convs = [ops.pack_conv(self.conv_seq[i].weight, self.conv_seq[i].bias, dtype=dt) for i in (0, 2, 4, 6)]
                 lin = ops.pack_conv(self.linear[0].weight, self.linear[0].bias,
-                                    (bn.weight, bn.bias, bn.running_mean, bn.running_var), bn_eps=bn.eps)
+                                    (bn.weight, bn.bias, bn.running_mean, bn.running_var), bn_eps=bn.eps, dtype=dt)
             self._trunk_pk, self._trunk_key = (convs, lin), key
         return self._trunk_pk
 
@@ -103,13 +104,13 @@ class MatchPredictor(nn.Module):
         for pc in convs:                       # 14 -> 12 -> 10 -> 8 -> 6, ReLU fused
             x = ops.conv2d(x, pc, relu=True)
         x = ops.avgpool(x)                     # AvgPool2d(6,6); the following ReLU is a no-op (x >= 0)
-        return ops.linear(x, lin)              # Linear + BatchNorm1d(eval) folded into the epilogue
+        return ops.linear(x, lin, out_f32=True)   # Linear + BatchNorm1d(eval) epilogue; descriptors are always fp32
 
     def trunk(self, x: torch.Tensor) -> torch.Tensor:
         """x NCHW [K,256,14,14] (the reference's layout) -> x3 [K,256]."""
         if self.linear[1].training and torch.is_grad_enabled():
             raise NotImplementedError("BatchNorm1d train mode / autograd is not built (SURVEY.md 8f row f2)")
-        return self.trunk_nhwc(ops.nchw_to_nhwc(x.detach()))
+        return self.trunk_nhwc(ops.nchw_to_nhwc(x.detach().to(torch.float32), getattr(self, "compute_dtype", torch.float32)))
 
     def pair(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         """x5 = last((a_i - b_j)^2): [Q,256] x [G,256] -> [Q,G,2]   (ref :73-74, :161-162)."""

@@ -173,6 +173,12 @@ class VideoMatchRCNN(nn.Module):
                                             box_detections_per_img)
         self._ignored_kwargs = kwargs       # training-only knobs of torchvision's MaskRCNN ctor
 
+    def set_compute_dtype(self, dtype: torch.dtype):
+        """torch.float32 (default: exact fp32 MFMA) or torch.float16 (fp16 MFMA with fp32 accumulation for
+        the extractor and the trunks -- BASELINE config 5; descriptors, NLB, match logits stay fp32)."""
+        det.set_compute_dtype(self, dtype)
+        return self
+
     def load_saved_matchrcnn(self, sd):
         """phase-1 -> phase-2 hand-off (ref :325-328)."""
         self.load_state_dict(sd, strict=False)

@@ -15,6 +15,7 @@ import torch
 from . import _native
 
 F32 = torch.float32
+F16 = torch.float16
 
 
 def _stream() -> int:
@@ -24,9 +25,17 @@ def _stream() -> int:
 def _req(t: torch.Tensor, dtype=F32, name: str = "tensor") -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _native.SeamNativeError(f"{name}: expected a tensor on the HIP device (no CPU path exists)")
-    if t.dtype != dtype:
+    if dtype is not None and t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _req_fp(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    """fp32 or fp16 activation (the two precisions the library computes in)."""
+    t = _req(t, None, name)
+    if t.dtype not in (F32, F16):
+        raise TypeError(f"{name}: expected float32 or float16, got {t.dtype}")
+    return t
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -47,6 +56,7 @@ class PackedConv:
     stride: int = 1
     pad: int = 0
     Cin: int = 0                    # real (unpadded) input channels: algorithmic FLOP accounting
+    dtype: torch.dtype = F32        # operand precision of the packed weights (fp32 | fp16)
 
 
 # When set to a list, every conv launch is bracketed by HIP events on the launch stream and
@@ -56,7 +66,7 @@ CONV_TRACE = None
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None, *, stride: int = 1,
               pad: int = 0, cstore: Optional[int] = None, transposed2x2: bool = False,
-              bn_eps: float = 1e-5) -> PackedConv:
+              bn_eps: float = 1e-5, dtype: torch.dtype = F32) -> PackedConv:
     """Pack a PyTorch-layout weight for ``conv2d``.
 
     weight: Conv2d [K,Cin,R,S] | Linear [K,Cin] | (transposed2x2) ConvTranspose2d [Cin,Cout,2,2]
@@ -75,12 +85,19 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         weight = weight.contiguous()
         K, cin, R, S = weight.shape
         mode = 0
-    cs = cstore if cstore is not None else ((cin + 3) // 4) * 4
+    epv = 4 if dtype == F32 else 8
+    cs = cstore if cstore is not None else ((cin + epv - 1) // epv) * epv
     rows = lib.seam_conv_rows_padded(K)
-    kred = lib.seam_conv_kred(cs, R, S)
-    wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
-    _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
-                  "seam_pack_conv_weight_f32")
+    if dtype == F32:
+        kred = lib.seam_conv_kred(cs, R, S)
+        wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
+        _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
+                      "seam_pack_conv_weight_f32")
+    else:
+        kred = lib.seam_conv_kred_f16(cs, R, S)
+        wp = torch.empty((rows, kred), dtype=F16, device=weight.device)
+        _native.check(lib.seam_pack_conv_weight_f16(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
+                      "seam_pack_conv_weight_f16")
     scale = shift = None
     if bias is not None:
         bias = bias.detach().to(F32)
@@ -95,89 +112,110 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         shift = shift.contiguous()
     elif bias is not None:
         shift = bias.contiguous()
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin)
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype)
 
 
 def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """NHWC implicit-GEMM conv (+scale/shift, +residual, +ReLU) -> NHWC [N,Ho,Wo,K]."""
-    x = _req(x, name="x")
+           out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """NHWC implicit-GEMM conv (+scale/shift, +residual, +ReLU) -> NHWC [N,Ho,Wo,K].
+    The precision (fp32 exact / fp16 MFMA with fp32 accumulate) is that of the packed weights;
+    ``out_f32`` makes the fp16 kernel write fp32 (hand-off to the fp32 descriptor heads)."""
+    x = _req(x, pc.dtype, "x")
     n, h, w, c = x.shape
     if c != pc.Cstore:
         raise ValueError(f"conv2d: input has {c} channels, weights packed for {pc.Cstore}")
     ho = (h + 2 * pc.pad - pc.R) // pc.stride + 1
     wo = (w + 2 * pc.pad - pc.S) // pc.stride + 1
-    y = out if out is not None else torch.empty((n, ho, wo, pc.K), dtype=F32, device=x.device)
+    ydt = F32 if (pc.dtype == F32 or out_f32) else F16
+    y = out if out is not None else torch.empty((n, ho, wo, pc.K), dtype=ydt, device=x.device)
     if residual is not None:
-        residual = _req(residual, name="residual")
+        residual = _req(residual, pc.dtype, "residual")
         if residual.shape != y.shape:
             raise ValueError("conv2d: residual shape mismatch")
     trace = CONV_TRACE
     if trace is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _native.check(_native.lib().seam_conv2d_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual),
-                                                _ptr(y), n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad,
-                                                1 if relu else 0, _stream()), "seam_conv2d_f32")
+    lib = _native.lib()
+    if pc.dtype == F32:
+        _native.check(lib.seam_conv2d_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
+                                          n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, 1 if relu else 0, _stream()),
+                      "seam_conv2d_f32")
+    else:
+        _native.check(lib.seam_conv2d_f16(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
+                                          n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, 1 if relu else 0,
+                                          1 if out_f32 else 0, _stream()), "seam_conv2d_f16")
     if trace is not None:
         e1.record()
-        variant = "conv_igemm_f32<128,128>" if pc.w.shape[0] % 128 == 0 else "conv_igemm_f32<128,64>"
+        tag = "float" if pc.dtype == F32 else "_Float16"
+        variant = f"conv_igemm<{tag},128,{128 if pc.w.shape[0] % 128 == 0 else 64}>"
+        es = x.element_size()
         trace.append((variant, 2.0 * n * ho * wo * pc.K * pc.R * pc.S * (pc.Cin or pc.Cstore), e0, e1,
                       (n, h, w, c, pc.K, pc.R, pc.stride),
-                      4.0 * (x.numel() + y.numel() * (2 if residual is not None else 1) + pc.w.numel())))
+                      float(es * (x.numel() + pc.w.numel()) + y.element_size() * y.numel()
+                            + (es * y.numel() if residual is not None else 0))))
     return y
 
 
-def linear(x: torch.Tensor, pc: PackedConv, relu: bool = False) -> torch.Tensor:
+def linear(x: torch.Tensor, pc: PackedConv, relu: bool = False, out_f32: bool = False) -> torch.Tensor:
     """[M,C] x packed [K,C] -> [M,K] through the conv kernel (1x1 on a 1x1 map)."""
     m, c = x.shape
-    return conv2d(x.view(m, 1, 1, c), pc, relu).view(m, pc.K)
+    return conv2d(x.view(m, 1, 1, c), pc, relu, out_f32=out_f32).view(m, pc.K)
 
 
 # ------------------------------------------------------------------------------ elementwise
-def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, wp: int) -> torch.Tensor:
-    """normalise + resize + pad + CHW->NHWC4 for a list of images -> [N,hp,wp,4]."""
+def _sfx(dtype) -> str:
+    return "f32" if dtype == F32 else "f16"
+
+
+def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, wp: int, dtype=F32) -> torch.Tensor:
+    """normalise + resize + pad + CHW->NHWC for a list of fp32 images -> [N,hp,wp,4] fp32 / [N,hp,wp,8] fp16."""
     lib = _native.lib()
-    out = torch.empty((len(images), hp, wp, 4), dtype=F32, device=images[0].device)
+    cs = 4 if dtype == F32 else 8
+    out = torch.empty((len(images), hp, wp, cs), dtype=dtype, device=images[0].device)
+    fn = lib.seam_preprocess_f32 if dtype == F32 else lib.seam_preprocess_f16
     for i, (img, (oh, ow)) in enumerate(zip(images, sizes)):
         img = _req(img, name="image")
         if img.dim() != 3 or img.shape[0] != 3:
             raise ValueError("images must be [3,H,W]")
-        _native.check(lib.seam_preprocess_f32(_ptr(img), C.c_void_p(out[i].data_ptr()), img.shape[1], img.shape[2],
-                                              oh, ow, hp, wp, _stream()), "seam_preprocess_f32")
+        _native.check(fn(_ptr(img), C.c_void_p(out[i].data_ptr()), img.shape[1], img.shape[2], oh, ow, hp, wp, _stream()),
+                      "seam_preprocess")
     return out
 
 
 def maxpool2d(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
-    x = _req(x)
+    x = _req_fp(x)
     n, h, w, c = x.shape
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-    y = torch.empty((n, ho, wo, c), dtype=F32, device=x.device)
-    _native.check(_native.lib().seam_maxpool2d_f32(_ptr(x), _ptr(y), n, h, w, c, k, stride, pad, _stream()),
-                  "seam_maxpool2d_f32")
+    y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    fn = getattr(_native.lib(), "seam_maxpool2d_" + _sfx(x.dtype))
+    _native.check(fn(_ptr(x), _ptr(y), n, h, w, c, k, stride, pad, _stream()), "seam_maxpool2d")
     return y
 
 
 def upsample_add_(lat: torch.Tensor, top: torch.Tensor) -> torch.Tensor:
-    lat, top = _req(lat), _req(top)
+    lat, top = _req_fp(lat), _req(top, lat.dtype)
     n, h, w, c = lat.shape
-    _native.check(_native.lib().seam_upsample_add_f32(_ptr(lat), _ptr(top), n, h, w, top.shape[1], top.shape[2], c,
-                                                      _stream()), "seam_upsample_add_f32")
+    fn = getattr(_native.lib(), "seam_upsample_add_" + _sfx(lat.dtype))
+    _native.check(fn(_ptr(lat), _ptr(top), n, h, w, top.shape[1], top.shape[2], c, _stream()), "seam_upsample_add")
     return lat
 
 
-def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+def nchw_to_nhwc(x: torch.Tensor, dtype=F32) -> torch.Tensor:
+    """fp32 [B,C,*sp] (the reference's layout) -> [B,*sp,C] in the library's compute dtype."""
     x = _req(x)
     b, c = x.shape[0], x.shape[1]
-    l = x[0, 0].numel()
-    y = torch.empty((b,) + tuple(x.shape[2:]) + (c,), dtype=F32, device=x.device)
+    l = x[0, 0].numel() if b else 0
+    y = torch.empty((b,) + tuple(x.shape[2:]) + (c,), dtype=dtype, device=x.device)
     if b:
-        _native.check(_native.lib().seam_nchw_to_nhwc_f32(_ptr(x), _ptr(y), b, c, l, _stream()), "seam_nchw_to_nhwc_f32")
+        fn = _native.lib().seam_nchw_to_nhwc_f32 if dtype == F32 else _native.lib().seam_nchw_f32_to_nhwc_f16
+        _native.check(fn(_ptr(x), _ptr(y), b, c, l, _stream()), "seam_nchw_to_nhwc")
     return y
 
 
 def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
-    x = _req(x)
+    """[B,*sp,C] fp32 / fp16 -> fp32 [B,C,*sp] (the reference's layout and dtype)."""
+    x = _req_fp(x)
     b, c = x.shape[0], x.shape[-1]
     sp = tuple(x.shape[1:-1])
     l = 1
@@ -185,39 +223,42 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
         l *= s
     y = torch.empty((b, c) + sp, dtype=F32, device=x.device)
     if b:
-        _native.check(_native.lib().seam_nhwc_to_nchw_f32(_ptr(x), _ptr(y), b, l, c, _stream()), "seam_nhwc_to_nchw_f32")
+        fn = _native.lib().seam_nhwc_to_nchw_f32 if x.dtype == F32 else _native.lib().seam_nhwc_f16_to_nchw_f32
+        _native.check(fn(_ptr(x), _ptr(y), b, l, c, _stream()), "seam_nhwc_to_nchw")
     return y
 
 
 def avgpool(x: torch.Tensor) -> torch.Tensor:
-    """NHWC [K,h,w,C] -> [K,C] mean over the spatial positions."""
-    x = _req(x)
+    """NHWC [K,h,w,C] -> [K,C] mean over the spatial positions (fp32 accumulate)."""
+    x = _req_fp(x)
     k, c = x.shape[0], x.shape[-1]
-    l = x[0].numel() // c
-    y = torch.empty((k, c), dtype=F32, device=x.device)
+    l = x[0].numel() // c if k else 0
+    y = torch.empty((k, c), dtype=x.dtype, device=x.device)
     if k:
-        _native.check(_native.lib().seam_avgpool_f32(_ptr(x), _ptr(y), k, l, c, _stream()), "seam_avgpool_f32")
+        fn = getattr(_native.lib(), "seam_avgpool_" + _sfx(x.dtype))
+        _native.check(fn(_ptr(x), _ptr(y), k, l, c, _stream()), "seam_avgpool")
     return y
 
 
 # ------------------------------------------------------------------------------ RoIAlign
 def roi_align(feats: Sequence[torch.Tensor], rois: torch.Tensor, scales: Sequence[float], pooled: int,
               sampling_ratio: int = 2, k_min: int = 2, levels: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """feats: 4 NHWC maps; rois [K,5] (batch_idx,x1,y1,x2,y2) -> NHWC [K,P,P,C]."""
-    feats = [_req(f) for f in feats]
+    """feats: 4 NHWC maps (fp32 or fp16); rois fp32 [K,5] (batch_idx,x1,y1,x2,y2) -> NHWC [K,P,P,C]."""
+    feats = [_req_fp(f) for f in feats]
+    dt = feats[0].dtype
     rois = _req(rois, name="rois")
     k = rois.shape[0]
     c = feats[0].shape[-1]
-    out = torch.empty((k, pooled, pooled, c), dtype=F32, device=rois.device)
+    out = torch.empty((k, pooled, pooled, c), dtype=dt, device=rois.device)
     if k == 0:
         return out
     hw = (C.c_int * 8)(*[d for f in feats for d in (f.shape[1], f.shape[2])])
     if levels is not None:
         levels = _req(levels, torch.int32, "levels")
-    _native.check(_native.lib().seam_roi_align_f32(_ptr(feats[0]), _ptr(feats[1]), _ptr(feats[2]), _ptr(feats[3]), hw,
-                                                   c, scales[0], scales[1], scales[2], scales[3], k_min, _ptr(rois),
-                                                   _ptr(levels), _ptr(out), k, pooled, sampling_ratio, _stream()),
-                  "seam_roi_align_f32")
+    fn = getattr(_native.lib(), "seam_roi_align_" + _sfx(dt))
+    _native.check(fn(_ptr(feats[0]), _ptr(feats[1]), _ptr(feats[2]), _ptr(feats[3]), hw, c, scales[0], scales[1],
+                     scales[2], scales[3], k_min, _ptr(rois), _ptr(levels), _ptr(out), k, pooled, sampling_ratio,
+                     _stream()), "seam_roi_align")
     return out
 
 
@@ -349,10 +390,10 @@ def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, hw) -> torch.Tensor:
 
 def mask_select(logits: torch.Tensor, labels: torch.Tensor, ncls: int) -> torch.Tensor:
     """logits [K,14,14,4*ncls] (sub-pixel groups) -> sigmoid prob of channel labels[k]: [K,1,28,28]."""
-    logits = _req(logits)
+    logits = _req_fp(logits)
     labels = _req(labels, torch.int64, "labels")
     k = logits.shape[0]
     out = torch.empty((k, 1, 28, 28), dtype=F32, device=logits.device)
-    _native.check(_native.lib().seam_mask_select_f32(_ptr(logits), _ptr(labels), _ptr(out), k, ncls, _stream()),
-                  "seam_mask_select_f32")
+    fn = getattr(_native.lib(), "seam_mask_select_" + _sfx(logits.dtype))
+    _native.check(fn(_ptr(logits), _ptr(labels), _ptr(out), k, ncls, _stream()), "seam_mask_select")
     return out

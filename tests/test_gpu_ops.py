@@ -286,3 +286,42 @@ def test_batched_nms_and_paste_masks(ops):
     ref = OD.paste_masks_in_image(masks, bx, (128, 192))
     got = ops.paste_masks(masks.to(d), bx.to(d), (128, 192))
     assert_close(got, ref, rtol=1e-5, atol_scale=1e-6)
+
+
+F16_CONV_CASES = [
+    # N, C, H, W, K, R, stride, pad, res, relu, out_f32
+    (2, 64, 20, 24, 64, 1, 1, 0, False, True, False),
+    (1, 64, 30, 26, 256, 1, 1, 0, True, True, False),
+    (2, 128, 17, 19, 128, 3, 1, 1, False, True, False),
+    (2, 128, 18, 22, 256, 3, 2, 1, False, True, False),
+    (1, 3, 64, 80, 64, 7, 2, 3, False, True, False),       # stem (3 -> 8 stored halves)
+    (3, 256, 14, 14, 256, 3, 1, 0, False, True, False),    # match trunk: valid 3x3
+    (1, 256, 13, 16, 15, 1, 1, 0, False, False, False),
+    (5, 1024, 1, 1, 256, 1, 1, 0, False, False, True),     # trunk Linear -> fp32 descriptors
+]
+
+
+@pytest.mark.parametrize("case", F16_CONV_CASES)
+def test_conv2d_f16(ops, case):
+    """fp16 MFMA path (config 5): operands rounded to fp16, fp32 accumulation -> compare against the
+    fp32 oracle evaluated on the SAME fp16-rounded operands (isolates the kernel from input rounding)."""
+    n, c, h, w, k, r, stride, pad, res, relu, out_f32 = case
+    x = rnd(1, (n, c, h, w)).half().float()
+    wt = (rnd(2, (k, c, r, r), "w") * (1.0 / math.sqrt(c * r * r))).half().float()
+    bias = rnd(3, (k,), "b") * 0.1
+    ref = F.conv2d(x, wt, bias, stride, pad)
+    resid = None
+    if res:
+        resid = rnd(8, ref.shape, "res").half().float()
+        ref = ref + resid
+    if relu:
+        ref = F.relu(ref)
+    d = dev()
+    pc = ops.pack_conv(wt.to(d), bias.to(d), stride=stride, pad=pad, dtype=torch.float16)
+    xin = nhwc(x)
+    if c % 8:
+        xin = F.pad(xin, (0, 8 - c % 8))
+    y = ops.conv2d(xin.half().to(d), pc, relu, None if resid is None else nhwc(resid).half().to(d), out_f32=out_f32)
+    assert y.dtype == (torch.float32 if out_f32 else torch.float16)
+    # fp32 accumulate; the only extra error is the final fp16 rounding of the output (2^-11 relative)
+    assert_close(y.float().permute(0, 3, 1, 2), ref, rtol=2e-3 if not out_f32 else 1e-3, atol_scale=1e-3)

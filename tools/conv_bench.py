@@ -10,18 +10,22 @@ DEFAULT = ["10,200,200,256,256,3,1,1,0", "320,14,14,256,256,3,1,1,0", "10,200,20
            "10,100,100,256,256,3,1,1,0", "10,50,50,256,256,3,1,1,0", "10,100,100,128,512,1,1,0,1",
            "10,50,50,256,1024,1,1,0,1", "320,8,8,256,1024,3,1,0,0", "10,200,200,64,64,3,1,1,0",
            "10,800,800,4,64,7,2,3,0", "10,25,25,256,256,3,1,1,0", "320,1,1,1024,256,1,1,0,0"]
-shapes = sys.argv[1:] or DEFAULT
+f16 = "--f16" in sys.argv
+dt = torch.float16 if f16 else torch.float32
+shapes = [a for a in sys.argv[1:] if not a.startswith("--")] or DEFAULT
 dev = torch.device("cuda:0")
 print(f"{'N,H,W,C,K,R,s,p,res':>30} {'us':>9} {'TF/s':>7} {'GB/s(alg)':>10}")
 for s in shapes:
     n, h, w, c, k, r, st, pad, res = map(int, s.split(","))
-    x = torch.randn(n, h, w, c, device=dev)
     cin = 3 if c == 4 else c
+    if f16 and c == 4:
+        c = 8
+    x = torch.randn(n, h, w, c, device=dev).to(dt)
     wt = torch.randn(k, cin, r, r, device=dev) * 0.05
-    pc = ops.pack_conv(wt, torch.randn(k, device=dev), stride=st, pad=pad, cstore=c)
+    pc = ops.pack_conv(wt, torch.randn(k, device=dev), stride=st, pad=pad, cstore=c, dtype=dt)
     ho, wo = (h + 2 * pad - r) // st + 1, (w + 2 * pad - r) // st + 1
-    resid = torch.randn(n, ho, wo, k, device=dev) if res else None
-    y = torch.empty(n, ho, wo, k, device=dev)
+    resid = torch.randn(n, ho, wo, k, device=dev).to(dt) if res else None
+    y = torch.empty(n, ho, wo, k, device=dev, dtype=dt)
     for _ in range(3):
         ops.conv2d(x, pc, True, resid, out=y)
     torch.cuda.synchronize()
@@ -33,5 +37,5 @@ for s in shapes:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     fl = 2.0 * n * ho * wo * k * r * r * cin
-    by = 4.0 * (x.numel() + y.numel() * (2 if res else 1) + pc.w.numel())
+    by = float(x.element_size()) * (x.numel() + y.numel() * (2 if res else 1) + pc.w.numel())
     print(f"{s:>30} {us:9.1f} {fl/us/1e6:7.1f} {by/us/1e3:10.0f}")

@@ -15,7 +15,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f"/tmp/pmc_{c}/p_counter_collection.csv")):
         name = r["Kernel_Name"]
-        key = "conv_igemm_f32<128,128>" if "conv_igemm_f32<128, 128" in name else ("conv_igemm_f32<128,64>" if "conv_igemm_f32<128, 64" in name else None)
+        key = None
+        for t in ("float", "_Float16"):
+            for bn in (128, 64):
+                if f"conv_igemm<{t}, 128, {bn}>" in name:
+                    key = f"conv_igemm<{t},128,{bn}>"
         if key and r["Counter_Name"] == c:
             agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
     out[c] = {k: {"launches": v[0], "avg_per_launch": v[1] / v[0], "total": v[1]} for k, v in agg.items()}
