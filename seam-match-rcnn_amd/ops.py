@@ -120,6 +120,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     """NHWC implicit-GEMM conv (+scale/shift, +residual, +ReLU) -> NHWC [N,Ho,Wo,K].
     The precision (fp32 exact / fp16 MFMA with fp32 accumulate) is that of the packed weights;
     ``out_f32`` makes the fp16 kernel write fp32 (hand-off to the fp32 descriptor heads)."""
+    x = _req(x, None, "x")             # device check first: CPU tensors fail loudly
     x = _req(x, pc.dtype, "x")
     n, h, w, c = x.shape
     if c != pc.Cstore:
