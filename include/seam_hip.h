@@ -54,6 +54,8 @@ const char* seam_error_string(int code);
  */
 int seam_conv_kred(int C, int R, int S);           /* host helper: ceil(R*S*C / 32) * 32 */
 int seam_conv_rows_padded(int K);                  /* host helper: ceil(K / 64) * 64      */
+int seam_conv_tile(int M, int K);                  /* host helper: BM*1000+BN of the block tile the launcher
+                                                      picks for an [M x K] output (128 or 64 each) */
 
 /* Pack an OIHW weight [K,Cin,R,S] (PyTorch layout) into the kernel's slab layout
  * (rows_padded*kred floats; reduction chunks ordered (r, c-chunk, s); channels >= Cin zero-filled).

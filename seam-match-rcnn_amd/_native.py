@@ -28,6 +28,7 @@ SIGNATURES = {
     "seam_error_string": (C.c_char_p, [_i]),
     "seam_conv_kred": (_i, [_i, _i, _i]),
     "seam_conv_rows_padded": (_i, [_i]),
+    "seam_conv_tile": (_i, [_i, _i]),
     "seam_pack_conv_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv_kred_f16": (_i, [_i, _i, _i]),

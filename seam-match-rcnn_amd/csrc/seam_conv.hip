@@ -53,6 +53,7 @@ struct ConvArgs {
     int M;
     int relu;
     int y_f32;         // fp16 kernel only: write fp32 output (descriptor heads stay fp32)
+    int slab_bn;       // rows per packed weight slab (128 or 64; fixed at pack time, >= the tile's BN)
     int tiles_m, tiles_n;
 };
 
@@ -100,8 +101,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.x + (size_t)n_first * img_elems * ES), 0,
         (int)(rem_bytes > kOob ? kOob : (unsigned)rem_bytes), 0x00020000);
+    // weight slabs are [n_slab][chunk][slab_bn][128 B]; a BN < slab_bn tile reads its rows inside each slab
+    const int slab_stride = p.slab_bn * CHUNK_BYTES;
+    const int n_in_slab = n0 % p.slab_bn;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.w + (size_t)n0 * p.kred * ES), 0, (int)((unsigned)BN * (unsigned)p.kred * ES), 0x00020000);
+        (void*)((const char*)p.w + (size_t)(n0 - n_in_slab) * p.kred * ES + (size_t)n_in_slab * CHUNK_BYTES), 0,
+        (int)((unsigned)nk * (unsigned)slab_stride), 0x00020000);
 
     int arow[AI], ahi[AI], awi[AI];      // byte offset of the (r=0,s=0,c=0) tap; top-left input coordinate
 #pragma unroll
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
         ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
     };
     auto load_b = [&](f32x4 (&br)[BI], int i) {
-        const int so = uq < nk ? uq * (BN * CHUNK_BYTES) : (int)kOob;
+        const int so = uq < nk ? uq * slab_stride : (int)kOob;
         br[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, brow[i], so, 0));
     };
     auto advance_k = [&]() {     // move on by one chunk
@@ -390,6 +395,24 @@ int pack_weight(const float* w, void* w_packed, int K, int Cin, int R, int S, in
     return (int)hipGetLastError();
 }
 
+// Tile choice: the per-CU serialised MFMA work is ~ ceil(blocks / 256 CUs) * BM * BN, weighted by the
+// measured relative cost per FLOP of each tile shape (smaller tiles move more operand bytes per FLOP);
+// take the cheapest: launches that cannot fill the chip with 128-row tiles get 64-row / 64-col tiles.
+inline void choose_tile(int M, int K, int& best_bm, int& best_bn) {
+    const int rows = ((K + 63) / 64) * 64;
+    const int slab = rows % 128 == 0 ? 128 : 64;
+    long best_cost = -1;
+    best_bm = 128;
+    best_bn = slab;
+    for (int bm = 128; bm >= 64; bm -= 64)
+        for (int bn = slab; bn >= 64; bn -= 64) {
+            const long nb = (long)((M + bm - 1) / bm) * (rows / bn);
+            const long w = (bm == 128 && bn == 128) ? 100 : (bm == 64 && bn == 64) ? 125 : 110;   // per-FLOP cost, %
+            const long cost = ((nb + 255) / 256) * bm * bn * w;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bm = bm; best_bn = bn; }
+        }
+}
+
 template <typename T>
 int conv2d(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, int y_f32, void* stream) {
@@ -407,14 +430,16 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.y_f32 = y_f32;
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
     const int rows = ((K + 63) / 64) * 64;
-    a.tiles_m = (a.M + 127) / 128;
-    if (rows % 128 == 0) {
-        a.tiles_n = rows / 128;
-        hipLaunchKernelGGL((conv_igemm<T, 128, 128>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
-    } else {
-        a.tiles_n = rows / 64;
-        hipLaunchKernelGGL((conv_igemm<T, 128, 64>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
-    }
+    a.slab_bn = rows % 128 == 0 ? 128 : 64;
+    int best_bm, best_bn;
+    choose_tile(a.M, K, best_bm, best_bn);
+    a.tiles_m = (a.M + best_bm - 1) / best_bm;
+    a.tiles_n = rows / best_bn;
+    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 128>), grid, block, 0, (hipStream_t)stream, a);
+    else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 64>), grid, block, 0, (hipStream_t)stream, a);
+    else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 64, 128>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_igemm<T, 64, 64>), grid, block, 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
@@ -425,6 +450,11 @@ extern "C" {
 int seam_conv_kred(int C, int R, int S) { return kred_of<float>(C, R, S); }
 int seam_conv_kred_f16(int C, int R, int S) { return kred_of<_Float16>(C, R, S); }
 int seam_conv_rows_padded(int K) { return ((K + 63) / 64) * 64; }
+int seam_conv_tile(int M, int K) {      // BM * 1000 + BN the launcher will pick for an [M x K] output
+    int bm, bn;
+    choose_tile(M, K, bm, bn);
+    return bm * 1000 + bn;
+}
 
 int seam_pack_conv_weight_f32(const float* w, float* w_packed, int K, int Cin, int R, int S, int Cstore, int mode,
                               void* stream) {

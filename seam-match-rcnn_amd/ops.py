@@ -149,7 +149,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     if trace is not None:
         e1.record()
         tag = "float" if pc.dtype == F32 else "_Float16"
-        variant = f"conv_igemm<{tag},128,{128 if pc.w.shape[0] % 128 == 0 else 64}>"
+        tile = lib.seam_conv_tile(n * ho * wo, pc.K)
+        variant = f"conv_igemm<{tag},{tile // 1000},{tile % 1000}>"
         es = x.element_size()
         trace.append((variant, 2.0 * n * ho * wo * pc.K * pc.R * pc.S * (pc.Cin or pc.Cstore), e0, e1,
                       (n, h, w, c, pc.K, pc.R, pc.stride),

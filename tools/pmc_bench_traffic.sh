@@ -17,9 +17,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         name = r["Kernel_Name"]
         key = None
         for t in ("float", "_Float16"):
-            for bn in (128, 64):
-                if f"conv_igemm<{t}, 128, {bn}>" in name:
-                    key = f"conv_igemm<{t},128,{bn}>"
+            for bm in (128, 64):
+                for bn in (128, 64):
+                    if f"conv_igemm<{t}, {bm}, {bn}>" in name:
+                        key = f"conv_igemm<{t},{bm},{bn}>"
         if key and r["Counter_Name"] == c:
             agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
     out[c] = {k: {"launches": v[0], "avg_per_launch": v[1] / v[0], "total": v[1]} for k, v in agg.items()}
