@@ -94,6 +94,12 @@ int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int ou
 int seam_preprocess_f16(const float* img, void* out /* fp16 NHWC8 */, int in_h, int in_w, int out_h,
                         int out_w, int Hp, int Wp, seam_stream_t stream);
 
+/* Same transform fed by a uint8 HWC RGB frame [in_h,in_w,3]: fuses ToTensor (x/255, stuffs/transform.py:46-49)
+ * so a clip crosses PCIe at 1 byte per sample (device side).  out: fp32 NHWC4 or, when
+ * out_f16 != 0, fp16 NHWC8. */
+int seam_preprocess_u8(const uint8_t* img, void* out, int in_h, int in_w, int out_h, int out_w,
+                       int Hp, int Wp, int out_f16, seam_stream_t stream);
+
 /* max_pool2d on NHWC [TV: ResNet stem 3x3/s2/p1; LastLevelMaxPool k=1,s=2]. C % 4 == 0. */
 int seam_maxpool2d_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride,
                        int pad, seam_stream_t stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "seam_pack_conv_weight_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_preprocess_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_maxpool2d_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_upsample_add_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -65,6 +65,42 @@ __global__ void preprocess_kernel(const float* __restrict__ img, T* __restrict__
     *reinterpret_cast<V*>(out + ((size_t)y * Wp + x) * Vec16<T>::N) = o;
 }
 
+// uint8 HWC RGB frame -> ToTensor (/255, ref stuffs/transform.py:46-49) + the transform above, one pass:
+// the clip crosses PCIe as 1 byte per sample instead of 4 (row f4, device side).
+template <typename T>
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ img, T* __restrict__ out, int in_h, int in_w,
+                                     int out_h, int out_w, int Hp, int Wp) {
+    typedef typename Vec16<T>::type V;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= Wp) return;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (y < out_h && x < out_w) {
+        const float mean[3] = {0.485f, 0.456f, 0.406f};
+        const float stdv[3] = {0.229f, 0.224f, 0.225f};
+        auto px = [&](int yy, int xx, int c) -> float {
+            return ((float)img[((size_t)yy * in_w + xx) * 3 + c] / 255.f - mean[c]) / stdv[c];
+        };
+        if (out_h == in_h && out_w == in_w) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = px(y, x, c);
+        } else {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilinear_axis(y, in_h, out_h, y0, y1, ly);
+            bilinear_axis(x, in_w, out_w, x0, x1, lx);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[c] = hy * (hx * px(y0, x0, c) + lx * px(y0, x1, c)) + ly * (hx * px(y1, x0, c) + lx * px(y1, x1, c));
+        }
+    }
+    V o;
+#pragma unroll
+    for (int c = 0; c < Vec16<T>::N; ++c) o[c] = (T)(c < 3 ? v[c] : 0.f);
+    *reinterpret_cast<V*>(out + ((size_t)y * Wp + x) * Vec16<T>::N) = o;
+}
+
 template <typename T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
                                int Ho, int Wo, int k, int stride, int pad) {
@@ -217,6 +253,18 @@ int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int ou
 }
 int seam_preprocess_f16(const float* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, void* stream) {
     return preprocess<_Float16>(img, out, in_h, in_w, out_h, out_w, Hp, Wp, stream);
+}
+
+int seam_preprocess_u8(const uint8_t* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, int out_f16,
+                       void* stream) {
+    dim3 grid((Wp + 255) / 256, Hp);
+    if (out_f16)
+        hipLaunchKernelGGL(preprocess_u8_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, img, (_Float16*)out, in_h,
+                           in_w, out_h, out_w, Hp, Wp);
+    else
+        hipLaunchKernelGGL(preprocess_u8_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)out, in_h, in_w,
+                           out_h, out_w, Hp, Wp);
+    return (int)hipGetLastError();
 }
 
 int seam_maxpool2d_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad, void* stream) {

@@ -65,7 +65,9 @@ class GeneralizedRCNNTransform(nn.Module):
     def forward(self, images: Sequence[torch.Tensor]):
         """list of [3,H,W] in [0,1] -> (NHWC batch [N,Hp,Wp,4] fp32 | [N,Hp,Wp,8] fp16, image_sizes,
         original_sizes)."""
-        orig = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]
+        # float [3,H,W] in [0,1] (the reference's input) or, as an extension, raw uint8 [H,W,3] frames
+        orig = [(int(i.shape[0]), int(i.shape[1])) if i.dtype == torch.uint8 else (int(i.shape[-2]), int(i.shape[-1]))
+                for i in images]
         sizes = [resized_size(h, w, self.min_size, self.max_size)[:2] for h, w in orig]
         d = self.size_divisible
         hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)

@@ -177,6 +177,13 @@ def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, 
     out = torch.empty((len(images), hp, wp, cs), dtype=dtype, device=images[0].device)
     fn = lib.seam_preprocess_f32 if dtype == F32 else lib.seam_preprocess_f16
     for i, (img, (oh, ow)) in enumerate(zip(images, sizes)):
+        if img.dtype == torch.uint8:        # extension: raw HWC RGB frame, ToTensor fused (row f4)
+            img = _req(img, torch.uint8, "image")
+            if img.dim() != 3 or img.shape[2] != 3:
+                raise ValueError("uint8 images must be [H,W,3]")
+            _native.check(lib.seam_preprocess_u8(_ptr(img), C.c_void_p(out[i].data_ptr()), img.shape[0], img.shape[1], oh, ow,
+                                                 hp, wp, 0 if dtype == F32 else 1, _stream()), "seam_preprocess_u8")
+            continue
         img = _req(img, name="image")
         if img.dim() != 3 or img.shape[0] != 3:
             raise ValueError("images must be [3,H,W]")

@@ -325,3 +325,16 @@ def test_conv2d_f16(ops, case):
     assert y.dtype == (torch.float32 if out_f32 else torch.float16)
     # fp32 accumulate; the only extra error is the final fp16 rounding of the output (2^-11 relative)
     assert_close(y.float().permute(0, 3, 1, 2), ref, rtol=2e-3 if not out_f32 else 1e-3, atol_scale=1e-3)
+
+
+def test_preprocess_uint8_frames(ops):
+    """row f4 (device side): uint8 HWC frame -> ToTensor + normalise + resize + pad in one kernel."""
+    d = dev()
+    raw = [(torch.from_numpy(synth.uniform(synth.stream_id(90 + i, "u8"), (60, 90, 3))) * 256).to(torch.uint8) for i in range(2)]
+    imgs = [r.permute(2, 0, 1).float().div(255) for r in raw]          # torchvision F.to_tensor semantics
+    ref, sizes = OD.transform(imgs, min_size=96, max_size=160)
+    out = ops.preprocess([r.to(d) for r in raw], [tuple(s) for s in sizes], ref.shape[-2], ref.shape[-1])
+    assert_close(out[..., :3].permute(0, 3, 1, 2), ref, atol_scale=1e-5)
+    ref1, sz1 = OD.transform(imgs, min_size=60, max_size=90)          # identity scale
+    out1 = ops.preprocess([r.to(d) for r in raw], [tuple(s) for s in sz1], ref1.shape[-2], ref1.shape[-1])
+    assert_close(out1[..., :3].permute(0, 3, 1, 2), ref1, atol_scale=1e-6)
