@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=T, help="frames of the clip the CPU baseline times")
+    ap.add_argument("--workload", choices=("c2", "c5"), default="c2",
+                    help="c2 (default, the BASELINE metric's config): 10 x 800x800 frames, 32 ROI/frame, fp32; "
+                         "c5: configs[4] per-GPU shape -- 30 x 1080x1920 frames, 64 ROI/frame (use with --dtype f16)")
     ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
                     help="f32 (default, the headline: exact fp32 MFMA) | f16 (config-5 style fp16 MFMA, fp32 accumulate; "
                          "extractor + trunks in fp16, descriptors / NLB / match logits fp32)")
@@ -70,6 +73,11 @@ def build_model(dev):
 
 def main():
     args = parse()
+    global T, R, H, W, FLOP_PER_CLIP
+    if args.workload == "c5":
+        T, R, H, W = 30, 64, 1080, 1920
+        # 1080p -> 749x1333 -> padded 768x1344: 387.1 GFLOP/frame
+        FLOP_PER_CLIP = T * 387.1e9 + T * R * (2 * 0.5338e9 + 1.033e9)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -97,7 +105,9 @@ def main():
     ta = model.roi_heads.temporal_aggregator
     frames = torch.from_numpy(synth.frames(rank, T, H, W)).to(dev)           # clip of this rank, resident
     frame_list = list(frames.unbind(0))
-    rois_np = synth.fixed_rois(R, H, W)
+    from seam_match_rcnn_amd.models.detection import resized_size
+    rh, rw, _ = resized_size(H, W)                                           # ROIs live in the resized frame
+    rois_np = synth.fixed_rois(R, rh, rw)
     rois = [torch.from_numpy(rois_np).to(dev) for _ in range(T)]
     types = torch.zeros(T * R, dtype=torch.int32)                            # all street ROIs (CPU, as the ref passes)
     ids = torch.arange(R, dtype=torch.int64).repeat(T)                       # sequence id = ROI slot
@@ -169,19 +179,22 @@ def main():
                                        for k, v in per.items() if k != dom}}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "c2":
         log("cpu baseline")
         cpu = cpu_baseline(sd, frames.cpu(), rois_np, args.cpu_frames)
         log("cpu baseline done")
 
     if rank == 0:
-        line = {"metric": "video-clips/sec (10f x 800^2, 32 ROI/f, 1k gallery)", "value": round(value, 4),
+        metric = ("video-clips/sec (10f x 800^2, 32 ROI/f, 1k gallery)" if args.workload == "c2"
+                  else "video-clips/sec (30f x 1080p, 64 ROI/f, 1k gallery)")
+        line = {"metric": metric, "value": round(value, 4),
                 "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": "configs[1] full pipeline, fixed ROIs: 10 frames 800x800 -> ResNet-50-FPN + RPN head "
-                                       "-> RoIAlign 14x14 (32 ROI/frame) -> mask head -> match trunk x2 -> SEAM NLB + "
-                                       "attention pool (32 seq x 10) -> pair logits vs 1000-product bank -> top-20",
+                "config": {"workload": ("configs[1]" if args.workload == "c2" else "configs[4] per-GPU shape") +
+                                       f" full pipeline, fixed ROIs: {T} frames {H}x{W} -> ResNet-50-FPN + RPN head "
+                                       f"-> RoIAlign 14x14 ({R} ROI/frame) -> mask head -> match trunk x2 -> SEAM NLB + "
+                                       f"attention pool ({R} seq x {T}) -> pair logits vs {G}-product bank -> top-{TOPK}",
                            "clips_per_step_per_gpu": 1, "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
                            "algorithmic_tflop_per_clip": round(FLOP_PER_CLIP / 1e12, 3),
                            "parallelism": f"dp{world} (clips sharded; product bank all-gathered over RCCL)"
