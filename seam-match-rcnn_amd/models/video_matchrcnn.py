@@ -83,6 +83,8 @@ class TemporalRoIHeads(nn.Module):
         # pad every image to the same number of proposals so the whole batch is filtered at once
         pmax = max(counts)
         c = (num_classes - 1) * pmax
+        if c > 16384:       # beyond the batched NMS kernel's per-image capacity (e.g. 91 classes): per-image path
+            return self._postprocess_per_image(boxes.view(-1, num_classes, 4), pred_scores, counts)
         pb = boxes.new_zeros((n_img, pmax, num_classes, 4))
         ps = pred_scores.new_full((n_img, pmax, num_classes), -1.0)
         row = torch.cat([torch.arange(k, device=dev) for k in counts])
@@ -97,6 +99,24 @@ class TemporalRoIHeads(nn.Module):
         ks, kl = torch.gather(ps, 1, order), torch.gather(labels, 1, order)
         kept = sel.sum(1).tolist()                                                           # one sync
         return (list(kb[sel].split(kept, 0)), list(ks[sel].split(kept, 0)), list(kl[sel].split(kept, 0)))
+
+    def _postprocess_per_image(self, boxes, scores, counts):
+        """Same rule as above for candidate sets too large for one batched NMS launch: filter first (one host
+        sync per image), and if more than 16384 candidates still pass the score threshold keep the 16384 best
+        (NMS keeps at most ``detections_per_img`` of them anyway)."""
+        num_classes = scores.shape[-1]
+        out_b, out_s, out_l = [], [], []
+        for b, s in zip(boxes.split(counts, 0), scores.split(counts, 0)):
+            labels = torch.arange(num_classes, device=s.device).view(1, -1).expand_as(s)
+            b, s, labels = b[:, 1:].reshape(-1, 4), s[:, 1:].flatten(), labels[:, 1:].flatten()
+            keep = (s > self.score_thresh) & ((b[:, 2] - b[:, 0]) >= 1e-2) & ((b[:, 3] - b[:, 1]) >= 1e-2)
+            b, s, labels = b[keep], s[keep], labels[keep]
+            if s.numel() > 16384:
+                top = torch.argsort(s, descending=True, stable=True)[:16384]
+                b, s, labels = b[top], s[top], labels[top]
+            k = det.batched_nms(b, s, labels, self.nms_thresh)[:self.detections_per_img]
+            out_b.append(b[k]); out_s.append(s[k]); out_l.append(labels[k])
+        return out_b, out_s, out_l
 
     def detect(self, features, proposals, image_shapes):
         """box branch (ref :225-253)."""

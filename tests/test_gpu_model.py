@@ -161,3 +161,57 @@ def test_full_forward_with_rpn(model_and_state):
         assert_close(o["scores"][:n // 2], r["scores"][:n // 2], rtol=5e-3)
         assert o["roi_features"].shape[1:] == (256, 14, 14)
         assert o["masks"].shape[-2:] == imgs[0].shape[-2:]
+
+
+def test_eval_with_targets_prepends_gt_boxes(model_and_state):
+    """ref models/video_matchrcnn.py:256-262: with targets in eval, GT boxes lead every image's detections (score 1)."""
+    m, sd = model_and_state
+    m.transform.min_size, m.transform.max_size = 192, 256                 # identity scale
+    imgs = [torch.from_numpy(synth.frames(30 + i, 1, 192, 256)[0]) for i in range(2)]
+    targets = [dict(boxes=torch.tensor([[10., 20., 120., 150.]]), labels=torch.tensor([3])),
+               dict(boxes=torch.tensor([[30., 40., 200., 180.], [5., 5., 60., 70.]]), labels=torch.tensor([1, 2]))]
+    with torch.no_grad():
+        out = m([i.to(dev()) for i in imgs], targets)
+        ref = m([i.to(dev()) for i in imgs])
+    for o, r, t in zip(out, ref, targets):
+        n = t["labels"].numel()
+        assert len(o["scores"]) == n + len(r["scores"])
+        assert torch.equal(o["scores"][:n].cpu(), torch.ones(n)) and torch.equal(o["labels"][:n].cpu(), t["labels"])
+        assert_close(o["boxes"][:n], t["boxes"], rtol=1e-6)
+        assert o["roi_features"].shape[0] == n + len(r["scores"]) == o["match_features"].shape[0]
+        assert_close(o["match_features"][n:], r["match_features"])
+    # the GT ROI's descriptor equals the oracle's trunk on the oracle's RoIAlign of that box
+    feats, sizes, padded = OM.extract_features(imgs, sd, 192, 256)
+    orf = OD.multiscale_roi_align([feats[k] for k in "0123"], [t["boxes"] for t in targets], sizes, 14)
+    ox3 = OH.match_trunk(orf, OM.sub(sd, "roi_heads.match_predictor."))
+    assert_close(torch.cat([out[0]["match_features"][:1], out[1]["match_features"][:2]]), ox3)
+
+
+def test_empty_detection_fallback_and_image_model(model_and_state):
+    """No detection above threshold -> the full-image fallback box (score 0.1 video / 1.0 image model, label 0):
+    ref models/video_matchrcnn.py:246-253, models/matchrcnn.py:373-379; the image model emits no roi_features."""
+    from seam_match_rcnn_amd.models.matchrcnn import matchrcnn_resnet50_fpn
+    m, sd = model_and_state
+    m.transform.min_size, m.transform.max_size = 128, 160
+    imgs = [torch.from_numpy(synth.frames(40 + i, 1, 128, 160)[0]).to(dev()) for i in range(2)]
+    old = m.roi_heads.score_thresh
+    m.roi_heads.score_thresh = 2.0
+    try:
+        with torch.no_grad():
+            out = m(imgs)
+    finally:
+        m.roi_heads.score_thresh = old
+    for o in out:
+        assert o["boxes"].cpu().tolist() == [[0.0, 0.0, 160.0, 128.0]]
+        assert o["labels"].cpu().tolist() == [0] and abs(float(o["scores"][0]) - 0.1) < 1e-7
+        assert o["roi_features"].shape == (1, 256, 14, 14) and o["masks"].shape == (1, 1, 128, 160)
+    m1 = matchrcnn_resnet50_fpn(pretrained_backbone=False, num_classes=14)
+    m1.load_state_dict({k: v for k, v in sd.items() if "temporal_aggregator" not in k})
+    m1 = m1.to(dev()).eval()
+    m1.transform.min_size, m1.transform.max_size = 128, 160
+    m1.roi_heads.score_thresh = 2.0
+    with torch.no_grad():
+        out1 = m1(imgs)
+    for o, ov in zip(out1, out):
+        assert "roi_features" not in o and abs(float(o["scores"][0]) - 1.0) < 1e-7
+        assert_close(o["match_features"], ov["match_features"])
