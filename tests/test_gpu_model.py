@@ -215,3 +215,29 @@ def test_empty_detection_fallback_and_image_model(model_and_state):
     for o, ov in zip(out1, out):
         assert "roi_features" not in o and abs(float(o["scores"][0]) - 1.0) < 1e-7
         assert_close(o["match_features"], ov["match_features"])
+
+
+def test_mixed_size_batch_full_forward(model_and_state):
+    """Images of different sizes in one batch (per-image resize, common zero-padded canvas, per-image clip in
+    the RPN / box decode): features, proposals-independent ROI features and detections vs the oracle."""
+    m, sd = model_and_state
+    m.transform.min_size, m.transform.max_size = 160, 288
+    imgs = [torch.from_numpy(synth.frames(60, 1, 150, 200)[0]), torch.from_numpy(synth.frames(61, 1, 180, 170)[0])]
+    with torch.no_grad():
+        feats, sizes, orig, padded = m.extract_features([i.to(dev()) for i in imgs])
+        out = m([i.to(dev()) for i in imgs])
+    ofe, osz, opad = OM.extract_features(imgs, sd, 160, 288)
+    assert [tuple(s) for s in osz] == [tuple(s) for s in sizes] and tuple(opad) == tuple(padded)
+    assert len({tuple(s) for s in sizes}) == 2
+    for k in ofe:
+        assert_close(feats[k].permute(0, 3, 1, 2), ofe[k])
+    props, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
+    ref = OM.detect(ofe, props, osz, sd, 0.1)
+    for o, r, sz, og in zip(out, ref, osz, orig):
+        n = min(len(o["scores"]), len(r["scores"]))
+        assert abs(len(o["scores"]) - len(r["scores"])) <= 2 and n > 0
+        assert_close(o["scores"][:n // 2], r["scores"][:n // 2], rtol=5e-3)
+        # boxes come back in ORIGINAL image pixels and inside the image
+        b = o["boxes"]
+        assert float(b[:, 0::2].max()) <= og[1] + 1e-3 and float(b[:, 1::2].max()) <= og[0] + 1e-3 and float(b.min()) >= 0
+        assert o["masks"].shape[-2:] == tuple(og)
