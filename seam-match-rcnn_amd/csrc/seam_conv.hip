@@ -28,6 +28,7 @@
 //   blockIdx -> tile mapping is XCD-aware (consecutive tiles stay on one XCD's L2; bijective form).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -436,10 +437,11 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.tiles_m = (a.M + best_bm - 1) / best_bm;
     a.tiles_n = rows / best_bn;
     const dim3 grid(a.tiles_m * a.tiles_n), block(256);
-    if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 128>), grid, block, 0, (hipStream_t)stream, a);
-    else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 64>), grid, block, 0, (hipStream_t)stream, a);
-    else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 64, 128>), grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv_igemm<T, 64, 64>), grid, block, 0, (hipStream_t)stream, a);
+    static const int dyn = getenv("SEAM_CONV_DYNLDS") ? atoi(getenv("SEAM_CONV_DYNLDS")) : 0;   // dev knob: occupancy experiments
+    if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 128>), grid, block, dyn, (hipStream_t)stream, a);
+    else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 64>), grid, block, dyn, (hipStream_t)stream, a);
+    else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 64, 128>), grid, block, dyn, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_igemm<T, 64, 64>), grid, block, dyn, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -11,8 +11,6 @@ DEFAULT = ["10,200,200,256,256,3,1,1,0", "320,14,14,256,256,3,1,1,0", "10,200,20
            "10,50,50,256,1024,1,1,0,1", "320,8,8,256,1024,3,1,0,0", "10,200,200,64,64,3,1,1,0",
            "10,800,800,4,64,7,2,3,0", "10,25,25,256,256,3,1,1,0", "320,1,1,1024,256,1,1,0,0"]
 f16 = "--f16" in sys.argv
-if "--nosplit" in sys.argv:
-    ops.CONV_SPLIT = False
 dt = torch.float16 if f16 else torch.float32
 shapes = [a for a in sys.argv[1:] if not a.startswith("--")] or DEFAULT
 dev = torch.device("cuda:0")
