@@ -14,7 +14,7 @@ namespace {
 
 constexpr int D = 256;       // descriptor width
 constexpr int DI = 128;      // NLB inter channels
-constexpr int RC = 8;        // rows per chunk
+constexpr int RC = 16;       // rows per chunk (a 10-frame sequence is one pass over the projection weights)
 constexpr int T_LDS = 96;    // sequences up to this length keep G/a/b in LDS
 
 __device__ __forceinline__ float wave_sum(float v) {

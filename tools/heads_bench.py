@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Timing of the SEAM head kernels at config-2 / config-3 sizes (GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import numpy as np
+import seam_match_rcnn_amd.synth as synth
+from seam_match_rcnn_amd import ops
+from seam_match_rcnn_amd.models.match_head import pack_nlb_from_state
+
+dev = torch.device("cuda:0")
+p = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in synth.temporal_aggregator_state(12).items()}
+pk = pack_nlb_from_state(p)
+
+def timeit(fn, reps=50):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+for s, t, g in ((32, 10, 1000), (256, 10, 20000), (64, 30, 1000)):
+    seq = torch.randn(t, s, 256, device=dev)
+    lens = torch.full((s,), t, dtype=torch.int32, device=dev)
+    gal = torch.randn(g, 256, device=dev)
+    a = torch.randn(s, 256, device=dev)
+    x5 = ops.pair_logits(a, gal, p["last.weight"], p["last.bias"])
+    print(f"S={s} T={t} G={g}: nlb+pool {timeit(lambda: ops.nlb_attnpool(seq, s*256, 256, lens, s, t, pk)):.1f} us | "
+          f"pair_logits {timeit(lambda: ops.pair_logits(a, gal, p['last.weight'], p['last.bias'])):.1f} us | "
+          f"rank_topk {timeit(lambda: ops.rank_topk(x5, 20)):.1f} us | "
+          f"pair_topk(fused) {timeit(lambda: ops.pair_topk(a, gal, p['last.weight'], p['last.bias'], 20)):.1f} us")
