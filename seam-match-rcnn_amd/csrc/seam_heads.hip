@@ -195,64 +195,120 @@ __global__ __launch_bounds__(256) void nlb_attnpool_kernel(const NlbArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pair logits: block tile (8*QT) x (32*GT) pairs, thread tile QT x GT, k chunks of 32 through LDS
+// pair logits: block tile (8*QT) x (32*GT) pairs, thread tile QT x GT, k chunks of 32 through LDS.
+// The two classes of a pair live in one float2 so the inner loop is packed fp32 math
+// (v_pk_add / v_pk_mul / v_pk_fma: the fp32 vector peak needs the packed forms): per k and per
+// (query, 2 products) one packed subtract + one packed square, per pair one packed fma into (x0, x1).
+// Same operation order per pair as the scalar form (sub, mul, fma chain over k) => bit-identical logits.
+// Chunks are software pipelined: next chunk global -> registers while the current one is consumed from
+// LDS, double-buffered LDS, one barrier per chunk.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int PKC = 32, PLD = PKC + 4;
+
 template <int QT, int GT>
-__global__ __launch_bounds__(256) void pair_logits_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ out, int Q, int G, int Dd) {
-    constexpr int KC = 32, LD = KC + 4;
+struct PairLds {
+    float as[2][8 * QT * PLD];
+    float bs[2][32 * GT * PLD];
+    float ws[2][2 * PKC];          // interleaved (w0[k], w1[k])
+};
+
+template <int QT, int GT>
+__device__ __forceinline__ void pair_tile(const float* __restrict__ a, const float* __restrict__ b,
+                                          const float* __restrict__ w, int q0, int g0, int Q, int G, int Dd,
+                                          PairLds<QT, GT>& L, f32x2 (&acc)[QT][GT]) {
     constexpr int BQ = 8 * QT, BG = 32 * GT;
-    __shared__ __attribute__((aligned(16))) float as[BQ * LD];
-    __shared__ __attribute__((aligned(16))) float bs[BG * LD];
-    __shared__ __attribute__((aligned(16))) float ws[2 * KC];
-    const int tid = threadIdx.x;
-    const int tx = tid & 31, ty = tid >> 5;
-    const int q0 = blockIdx.y * BQ, g0 = blockIdx.x * BG;
-    float acc0[QT][GT], acc1[QT][GT];
+    constexpr int NA = (BQ * (PKC / 4) + 255) / 256, NB = (BG * (PKC / 4)) / 256;
+    static_assert(GT % 2 == 0 && (BG * (PKC / 4)) % 256 == 0, "tile shape");
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    f32x4 ra[NA], rb[NB];
+    float rw = 0.f;
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int i = tid + 256 * t, r = i / (PKC / 4), c = i % (PKC / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < BQ * (PKC / 4) && q0 + r < Q) v = *reinterpret_cast<const f32x4*>(a + (size_t)(q0 + r) * Dd + k0 + c * 4);
+            ra[t] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int i = tid + 256 * t, r = i / (PKC / 4), c = i % (PKC / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (g0 + r < G) v = *reinterpret_cast<const f32x4*>(b + (size_t)(g0 + r) * Dd + k0 + c * 4);
+            rb[t] = v;
+        }
+        if (tid < 2 * PKC) rw = w[(size_t)(tid & 1) * Dd + k0 + (tid >> 1)];
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int i = tid + 256 * t, r = i / (PKC / 4), c = i % (PKC / 4);
+            if (i < BQ * (PKC / 4)) *reinterpret_cast<f32x4*>(&L.as[buf][r * PLD + c * 4]) = ra[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int i = tid + 256 * t, r = i / (PKC / 4), c = i % (PKC / 4);
+            *reinterpret_cast<f32x4*>(&L.bs[buf][r * PLD + c * 4]) = rb[t];
+        }
+        if (tid < 2 * PKC) L.ws[buf][tid] = rw;
+    };
 #pragma unroll
     for (int i = 0; i < QT; ++i)
 #pragma unroll
-        for (int j = 0; j < GT; ++j) { acc0[i][j] = 0.f; acc1[i][j] = 0.f; }
+        for (int j = 0; j < GT; ++j) acc[i][j] = (f32x2){0.f, 0.f};
 
-    for (int k0 = 0; k0 < Dd; k0 += KC) {
-        __syncthreads();
-        for (int i = tid; i < BQ * (KC / 4); i += 256) {
-            const int r = i / (KC / 4), c = i % (KC / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q0 + r < Q) v = *reinterpret_cast<const f32x4*>(a + (size_t)(q0 + r) * Dd + k0 + c * 4);
-            *reinterpret_cast<f32x4*>(&as[r * LD + c * 4]) = v;
-        }
-        for (int i = tid; i < BG * (KC / 4); i += 256) {
-            const int r = i / (KC / 4), c = i % (KC / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g0 + r < G) v = *reinterpret_cast<const f32x4*>(b + (size_t)(g0 + r) * Dd + k0 + c * 4);
-            *reinterpret_cast<f32x4*>(&bs[r * LD + c * 4]) = v;
-        }
-        if (tid < 2 * KC) ws[tid] = w[(size_t)(tid / KC) * Dd + k0 + (tid % KC)];
-        __syncthreads();
+    gload(0);
+    __syncthreads();                 // previous user of the LDS buffers is done
+    lstore(0);
+    __syncthreads();
+    const int nch = Dd / PKC;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nch) gload((ch + 1) * PKC);
+        const float* as = L.as[buf];
+        const float* bs = L.bs[buf];
+        const float* ws = L.ws[buf];
 #pragma unroll
-        for (int k4 = 0; k4 < KC; k4 += 4) {
+        for (int k4 = 0; k4 < PKC; k4 += 4) {
             f32x4 av[QT], bv[GT];
 #pragma unroll
-            for (int i = 0; i < QT; ++i) av[i] = *reinterpret_cast<const f32x4*>(&as[(ty * QT + i) * LD + k4]);
+            for (int i = 0; i < QT; ++i) av[i] = *reinterpret_cast<const f32x4*>(&as[(ty * QT + i) * PLD + k4]);
 #pragma unroll
-            for (int j = 0; j < GT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bs[(tx + 32 * j) * LD + k4]);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&ws[k4]);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&ws[KC + k4]);
+            for (int j = 0; j < GT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bs[(tx + 32 * j) * PLD + k4]);
+            f32x2 wk[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wk[kk] = *reinterpret_cast<const f32x2*>(&ws[(k4 + kk) * 2]);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < QT; ++i)
 #pragma unroll
-                    for (int j = 0; j < GT; ++j) {
-                        const float d = av[i][kk] - bv[j][kk];
-                        const float d2 = d * d;
-                        acc0[i][j] = fmaf(d2, w0[kk], acc0[i][j]);
-                        acc1[i][j] = fmaf(d2, w1[kk], acc1[i][j]);
+                    for (int j = 0; j < GT; j += 2) {
+                        const f32x2 aa = {av[i][kk], av[i][kk]};
+                        const f32x2 bb = {bv[j][kk], bv[j + 1][kk]};
+                        const f32x2 d = aa - bb;
+                        const f32x2 d2 = d * d;
+                        acc[i][j] = __builtin_elementwise_fma((f32x2){d2.x, d2.x}, wk[kk], acc[i][j]);
+                        acc[i][j + 1] = __builtin_elementwise_fma((f32x2){d2.y, d2.y}, wk[kk], acc[i][j + 1]);
                     }
         }
+        if (ch + 1 < nch) lstore(buf ^ 1);
+        __syncthreads();
     }
-    const float b0 = bias[0], b1 = bias[1];
+}
+
+template <int QT, int GT>
+__global__ __launch_bounds__(256) void pair_logits_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int Q, int G, int Dd) {
+    constexpr int BQ = 8 * QT, BG = 32 * GT;
+    __shared__ __attribute__((aligned(16))) PairLds<QT, GT> L;
+    const int tid = threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
+    const int q0 = blockIdx.y * BQ, g0 = blockIdx.x * BG;
+    f32x2 acc[QT][GT];
+    pair_tile<QT, GT>(a, b, w, q0, g0, Q, G, Dd, L, acc);
+    const f32x2 bz = {bias[0], bias[1]};
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
         const int qi = q0 + ty * QT + i;
@@ -260,68 +316,130 @@ __global__ __launch_bounds__(256) void pair_logits_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < GT; ++j) {
             const int gj = g0 + tx + 32 * j;
-            if (gj < G) {
-                float2 v = make_float2(acc0[i][j] + b0, acc1[i][j] + b1);
-                *reinterpret_cast<float2*>(out + ((size_t)qi * G + gj) * 2) = v;
-            }
+            if (gj < G) *reinterpret_cast<f32x2*>(out + ((size_t)qi * G + gj) * 2) = acc[i][j] + bz;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// rank_topk: one workgroup per query; k rounds of arg-max over d = x1 - x0 with the strict total
-// order (d desc, index asc); the previous winner bounds the next round (no scratch, no mutation).
-__global__ __launch_bounds__(256) void rank_topk_kernel(const float* __restrict__ logits, int64_t* __restrict__ idx,
-                                                        float* __restrict__ score, int G, int k) {
-    __shared__ float rv[4];
-    __shared__ int ri[4];
-    __shared__ float bestv;
-    __shared__ int besti;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const float2* row = reinterpret_cast<const float2*>(logits) + (size_t)q * G;
-    float pv = INFINITY;
-    int pi = -1;
-    for (int round = 0; round < k; ++round) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int g = tid; g < G; g += 256) {
-            const float2 x = row[g];
-            float d = x.y - x.x;
-            if (d != d) d = -INFINITY;                                  // NaN ranks last
-            const bool elig = (d < pv) || (d == pv && g > pi);           // strictly after the previous winner
-            if (elig && (d > bv || (d == bv && g < bi))) { bv = d; bi = g; }
+// Exact top-k of one row of n (x0, x1) pairs under the strict order (d = x1 - x0 descending, index
+// ascending), O(n) instead of k arg-max rounds: an MSB-first 8-bit radix select over order-preserving
+// keys finds the k-th largest key T (4 histogram passes in LDS), everything above T is collected with
+// one pass, ties at T are taken lowest-index-first, and the k winners are ordered by rank counting.
+// Item j of the row is (x0, x1, g) = load(j); g is the value reported as its index.
+__device__ __forceinline__ unsigned tk_key(float x0, float x1) {
+    float d = x1 - x0;
+    if (d != d) d = -INFINITY;                   // NaN ranks last
+    d += 0.f;                                    // -0 -> +0 (equal scores must tie)
+    const unsigned u = __float_as_uint(d);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct TopkShared {
+    unsigned hist[256];
+    unsigned key[256];
+    int item[256];
+    int gidx[256];
+    unsigned prefix, krem, cnt;
+    int red[4];
+};
+
+template <typename Load>
+__device__ void block_topk(Load load, int n, int k, int64_t* __restrict__ idx_out, float* __restrict__ score_out,
+                           TopkShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    unsigned prefix = 0, mask = 0, krem = (unsigned)k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        sh.hist[tid] = 0;
+        __syncthreads();
+        for (int j = tid; j < n; j += 256) {
+            float x0, x1; int g;
+            load(j, x0, x1, g);
+            const unsigned key = g < 0 ? 0u : tk_key(x0, x1);
+            if (g >= 0 && (key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0;
+            int bsel = 0;
+            for (int bb = 255; bb >= 0; --bb) {
+                if (cum + sh.hist[bb] >= krem) { bsel = bb; break; }
+                cum += sh.hist[bb];
+            }
+            sh.prefix = prefix | ((unsigned)bsel << shift);
+            sh.krem = krem - cum;
+        }
+        __syncthreads();
+        prefix = sh.prefix;
+        krem = sh.krem;
+        mask |= 0xFFu << shift;
+    }
+    const unsigned T = prefix;                   // k-th largest key; krem (>= 1) of the items equal to T are taken
+    const int nabove = k - (int)krem;
+    if (tid == 0) sh.cnt = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        float x0, x1; int g;
+        load(j, x0, x1, g);
+        if (g < 0) continue;
+        const unsigned key = tk_key(x0, x1);
+        if (key > T) {
+            const unsigned pos = atomicAdd(&sh.cnt, 1u);
+            sh.key[pos] = key; sh.item[pos] = j; sh.gidx[pos] = g;
+        }
+    }
+    __syncthreads();
+    int last = -1;
+    for (unsigned r = 0; r < krem; ++r) {        // ties at T: lowest reported index first (usually one round)
+        int best = 0x7fffffff, bestj = -1;
+        for (int j = tid; j < n; j += 256) {
+            float x0, x1; int g;
+            load(j, x0, x1, g);
+            if (g > last && g < best && tk_key(x0, x1) == T) { best = g; bestj = j; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            const int ob = __shfl_xor(best, o, 64), oj = __shfl_xor(bestj, o, 64);
+            if (ob < best) { best = ob; bestj = oj; }
         }
-        if (lane == 0) { rv[wid] = bv; ri[wid] = bi; }
+        if (lane == 0) { sh.red[wid] = best; sh.hist[wid] = (unsigned)bestj; }
         __syncthreads();
         if (tid == 0) {
-            float v = rv[0];
-            int i = ri[0];
-            for (int w = 1; w < 4; ++w)
-                if (rv[w] > v || (rv[w] == v && ri[w] < i)) { v = rv[w]; i = ri[w]; }
-            bestv = v;
-            besti = i;
-            const bool found = i != 0x7fffffff;
-            idx[(size_t)q * k + round] = found ? (int64_t)i : (int64_t)-1;
-            float sc = 0.f;
-            if (found) {
-                const float2 x = row[i];
-                const float mx = fmaxf(x.x, x.y);                        // softmax(x)[1]
-                const float e0 = expf(x.x - mx), e1 = expf(x.y - mx);
-                sc = e1 / (e0 + e1);
-            }
-            score[(size_t)q * k + round] = sc;
+            int bb = sh.red[0], bj = (int)sh.hist[0];
+            for (int w2 = 1; w2 < 4; ++w2)
+                if (sh.red[w2] < bb) { bb = sh.red[w2]; bj = (int)sh.hist[w2]; }
+            sh.key[nabove + r] = T; sh.item[nabove + r] = bj; sh.gidx[nabove + r] = bb;
+            sh.red[0] = bb;
         }
         __syncthreads();
-        pv = bestv;
-        pi = besti;
+        last = sh.red[0];
         __syncthreads();
     }
+    if (tid < k) {                               // order the k winners by counting (k <= 256)
+        const unsigned mk = sh.key[tid];
+        const int mg = sh.gidx[tid], mj = sh.item[tid];
+        int rank = 0;
+        for (int j = 0; j < k; ++j) rank += (sh.key[j] > mk || (sh.key[j] == mk && sh.gidx[j] < mg)) ? 1 : 0;
+        float sc = 0.f;
+        if (mj >= 0) {
+            float x0, x1; int g;
+            load(mj, x0, x1, g);
+            const float mx = fmaxf(x0, x1);
+            const float e0 = expf(x0 - mx), e1 = expf(x1 - mx);
+            sc = e1 / (e0 + e1);                 // softmax(x)[1]
+        }
+        idx_out[rank] = mj >= 0 ? (int64_t)mg : (int64_t)-1;
+        score_out[rank] = sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_topk_kernel(const float* __restrict__ logits, int64_t* __restrict__ idx,
+                                                        float* __restrict__ score, int G, int k) {
+    __shared__ TopkShared sh;
+    const int q = blockIdx.x;
+    const float2* row = reinterpret_cast<const float2*>(logits) + (size_t)q * G;
+    block_topk([&](int j, float& x0, float& x1, int& g) { const float2 x = row[j]; x0 = x.x; x1 = x.y; g = j; }, G, k,
+               idx + (size_t)q * k, score + (size_t)q * k, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,10 +454,8 @@ __device__ __forceinline__ bool tk_better(float d, int g, float bd, int bg) { re
 __global__ __launch_bounds__(256) void pair_topk_stage1(const float* __restrict__ a, const float* __restrict__ b,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         float* __restrict__ cand, int Q, int G, int Dd, int k, int nseg) {
-    constexpr int KC = 32, LD = KC + 4, BQ = 32, BG = 128;
-    __shared__ __attribute__((aligned(16))) float as[BQ * LD];
-    __shared__ __attribute__((aligned(16))) float bs[BG * LD];
-    __shared__ __attribute__((aligned(16))) float ws[2 * KC];
+    constexpr int BQ = 32, BG = 128;
+    __shared__ __attribute__((aligned(16))) PairLds<4, 4> L;
     __shared__ float L0[BQ][TK_SEG + 1];
     __shared__ float L1[BQ][TK_SEG + 1];
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, lane = tid & 63, wid = tid >> 6;
@@ -347,55 +463,14 @@ __global__ __launch_bounds__(256) void pair_topk_stage1(const float* __restrict_
     const float b0 = bias[0], b1 = bias[1];
     for (int sub = 0; sub < TK_SEG / BG; ++sub) {
         const int g0 = gseg + sub * BG;
-        float acc0[4][4], acc1[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc0[i][j] = 0.f; acc1[i][j] = 0.f; }
-        for (int k0 = 0; k0 < Dd; k0 += KC) {
-            __syncthreads();
-            for (int i = tid; i < BQ * (KC / 4); i += 256) {
-                const int r = i / (KC / 4), c = i % (KC / 4);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (q0 + r < Q) v = *reinterpret_cast<const f32x4*>(a + (size_t)(q0 + r) * Dd + k0 + c * 4);
-                *reinterpret_cast<f32x4*>(&as[r * LD + c * 4]) = v;
-            }
-            for (int i = tid; i < BG * (KC / 4); i += 256) {
-                const int r = i / (KC / 4), c = i % (KC / 4);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (g0 + r < G) v = *reinterpret_cast<const f32x4*>(b + (size_t)(g0 + r) * Dd + k0 + c * 4);
-                *reinterpret_cast<f32x4*>(&bs[r * LD + c * 4]) = v;
-            }
-            if (tid < 2 * KC) ws[tid] = w[(size_t)(tid / KC) * Dd + k0 + (tid % KC)];
-            __syncthreads();
-#pragma unroll
-            for (int k4 = 0; k4 < KC; k4 += 4) {
-                f32x4 av[4], bv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(&as[(ty * 4 + i) * LD + k4]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bs[(tx + 32 * j) * LD + k4]);
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(&ws[k4]);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&ws[KC + k4]);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float d = av[i][kk] - bv[j][kk];
-                            const float d2 = d * d;
-                            acc0[i][j] = fmaf(d2, w0[kk], acc0[i][j]);
-                            acc1[i][j] = fmaf(d2, w1[kk], acc1[i][j]);
-                        }
-            }
-        }
+        f32x2 acc[4][4];
+        pair_tile<4, 4>(a, b, w, q0, g0, Q, G, Dd, L, acc);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                L0[ty * 4 + i][sub * BG + tx + 32 * j] = acc0[i][j] + b0;
-                L1[ty * 4 + i][sub * BG + tx + 32 * j] = acc1[i][j] + b1;
+                L0[ty * 4 + i][sub * BG + tx + 32 * j] = acc[i][j].x + b0;
+                L1[ty * 4 + i][sub * BG + tx + 32 * j] = acc[i][j].y + b1;
             }
     }
     __syncthreads();
@@ -443,56 +518,11 @@ __global__ __launch_bounds__(256) void pair_topk_stage1(const float* __restrict_
 
 __global__ __launch_bounds__(256) void pair_topk_stage2(const float* __restrict__ cand, int64_t* __restrict__ idx,
                                                         float* __restrict__ score, int ncand, int k) {
-    __shared__ float rv[4];
-    __shared__ int ri[4], rc[4];
-    __shared__ float bestv;
-    __shared__ int besti, bestc;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    __shared__ TopkShared sh;
+    const int q = blockIdx.x;
     const float* c = cand + (size_t)q * ncand * 3;
-    float pv = INFINITY;
-    int pi = -1;
-    for (int round = 0; round < k; ++round) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff, bc = -1;
-        for (int j = tid; j < ncand; j += 256) {
-            const int g = __float_as_int(c[j * 3 + 2]);
-            if (g < 0) continue;
-            float d = c[j * 3 + 1] - c[j * 3];
-            if (d != d) d = -INFINITY;
-            const bool elig = (d < pv) || (d == pv && g > pi);
-            if (elig && tk_better(d, g, bv, bi)) { bv = d; bi = g; bc = j; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            const int oc = __shfl_xor(bc, o, 64);
-            if (tk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; bc = oc; }
-        }
-        if (lane == 0) { rv[wid] = bv; ri[wid] = bi; rc[wid] = bc; }
-        __syncthreads();
-        if (tid == 0) {
-            float v = rv[0];
-            int i = ri[0], cc = rc[0];
-            for (int w2 = 1; w2 < 4; ++w2)
-                if (tk_better(rv[w2], ri[w2], v, i)) { v = rv[w2]; i = ri[w2]; cc = rc[w2]; }
-            bestv = v; besti = i; bestc = cc;
-            const bool found = i != 0x7fffffff;
-            idx[(size_t)q * k + round] = found ? (int64_t)i : (int64_t)-1;
-            float sc = 0.f;
-            if (found) {
-                const float x0 = c[cc * 3], x1 = c[cc * 3 + 1];
-                const float mx = fmaxf(x0, x1);
-                const float e0 = expf(x0 - mx), e1 = expf(x1 - mx);
-                sc = e1 / (e0 + e1);
-            }
-            score[(size_t)q * k + round] = sc;
-        }
-        __syncthreads();
-        pv = bestv;
-        pi = besti;
-        __syncthreads();
-    }
+    block_topk([&](int j, float& x0, float& x1, int& g) { x0 = c[j * 3]; x1 = c[j * 3 + 1]; g = __float_as_int(c[j * 3 + 2]); },
+               ncand, k, idx + (size_t)q * k, score + (size_t)q * k, sh);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -111,9 +111,9 @@ def match_sequences(aggregator, x3_1b: torch.Tensor, bank: torch.Tensor, k: int 
 
 @torch.no_grad()
 def match_sequences_topk(aggregator, x3_1b: torch.Tensor, bank: torch.Tensor, k: int = 20):
-    """Same ranking as ``match_sequences`` without materialising the [S,G,2] logits (fused
-    ``seam_pair_topk_f32``): for large galleries (configs 3/4: G = 20 000 / 50 000) the logits tensor
-    is the dominant HBM traffic of the stage.  -> (idx [S,k] int64, score [S,k])."""
+    """Same ranking as ``match_sequences`` without materialising the full [S,G,2] logits (query chunks
+    through a reused, cache-resident logits buffer; see ``ops.pair_topk``) for large galleries
+    (configs 3/4: G = 20 000 / 50 000).  -> (idx [S,k] int64, score [S,k])."""
     from . import ops
     return ops.pair_topk(x3_1b, bank, aggregator.last.weight, aggregator.last.bias, min(k, bank.shape[0]))
 

@@ -49,8 +49,10 @@ def test_config3_mode_b_8clips_20000_gallery(ta):
     idx, sc = ops.rank_topk(x5, 20)
     ridx, rsc = OH.rank_topk(x5.cpu(), 20)
     assert torch.equal(idx.cpu(), ridx)
-    fidx, fsc = retrieval.match_sequences_topk(m, x3_1b, gal.to(dev()), 20)      # fused: no [S,G,2] in HBM
+    fidx, fsc = retrieval.match_sequences_topk(m, x3_1b, gal.to(dev()), 20)      # chunked: no full [S,G,2] in HBM
     assert torch.equal(fidx, idx) and torch.equal(fsc, sc)
+    f2idx, f2sc = ops.pair_topk(x3_1b, gal.to(dev()), m.last.weight, m.last.bias, 20, fused=True)   # single-pass kernel
+    assert torch.equal(f2idx, idx) and torch.equal(f2sc, sc)
     oidx, _ = OH.rank_topk(ref5, 20)
     agree = np.mean([len(set(a.tolist()) & set(b.tolist())) / 20.0 for a, b in zip(idx.cpu(), oidx)])
     assert agree > 0.995, agree
@@ -78,7 +80,7 @@ def test_config4_shard_sized_match_50000_gallery(ta):
     assert torch.equal(perm.to(dev())[pidx], idx)
     assert torch.equal(psc, sc)
     # small-k / k == G edge cases of the fused kernel
-    i1, s1 = ops.pair_topk(ad[:3], bd[:7], m.last.weight, m.last.bias, 7)
+    i1, s1 = ops.pair_topk(ad[:3], bd[:7], m.last.weight, m.last.bias, 7, fused=True)
     i2, s2 = ops.rank_topk(ops.pair_logits(ad[:3], bd[:7], m.last.weight, m.last.bias), 7)
     assert torch.equal(i1, i2) and torch.equal(s1, s2)
 
