@@ -68,6 +68,32 @@ def plan_sequences(types_c: torch.Tensor, ids_c: torch.Tensor):
     return sel0, order, pos, seq_of_row, counts
 
 
+_PLAN_CACHE = {}     # (types bytes, ids bytes, device) -> device-resident packing plan of Mode A
+
+
+def device_plan(types_c: torch.Tensor, ids_c: torch.Tensor, dev: torch.device):
+    """``plan_sequences`` with its index tensors uploaded once per distinct (types, ids): callers such as the
+    evaluator / the bench pass the same layout for every clip, so steady-state calls issue no host-to-device
+    copies (and stay capturable in a HIP graph)."""
+    key = (types_c.numpy().tobytes(), ids_c.numpy().tobytes(), str(types_c.dtype), str(ids_c.dtype), str(dev))
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        sel0, order, pos, seq_of_row, counts = plan_sequences(types_c, ids_c)
+        n_seqs = int(counts.numel())
+        maxlen = int(counts.max()) if n_seqs else 0
+        plan = dict(
+            n0=int(sel0.numel()), n_seqs=n_seqs, maxlen=maxlen, counts=counts,
+            rows=sel0[order].to(dev), pos1=(pos + 1).to(dev), seq_of_row=seq_of_row.to(dev),
+            sel1=(types_c == 1).nonzero().view(-1).to(dev),
+            mask=(torch.arange(1 + maxlen)[None, :] > counts[:, None]).to(dev) if n_seqs else None,
+            lens=counts.to(torch.int32).to(dev) if n_seqs else None,
+            ids0=ids_c[sel0])
+        if len(_PLAN_CACHE) > 64:
+            _PLAN_CACHE.clear()
+        _PLAN_CACHE[key] = plan
+    return plan
+
+
 class MatchPredictor(nn.Module):
     def __init__(self):
         super().__init__()
@@ -150,19 +176,17 @@ class TemporalAggregationNLB(MatchPredictor):
             dev = x3.device
             types_c = torch.as_tensor(types).cpu()
             ids_c = torch.as_tensor(ids).cpu()
-            sel0, order, pos, seq_of_row, counts = plan_sequences(types_c, ids_c)
-            x3_1_ids_c = ids_c[sel0]
-            x3_2 = x3[(types_c == 1).to(dev)]
-            if x3_1_ids_c.numel() > 0:
+            plan = device_plan(types_c, ids_c, dev)
+            x3_1_ids_c = plan["ids0"]
+            x3_2 = x3[plan["sel1"]]
+            if plan["n0"] > 0:
                 # packing rules: sequences ordered by sorted unique id; maxlen = modal count;
                 # dummy zero row 0; mask True on padding (ref :98-111)
-                n_seqs, maxlen = int(counts.numel()), int(counts.max())
+                n_seqs, maxlen, counts = plan["n_seqs"], plan["maxlen"], plan["counts"]
                 x3_1_seq = torch.zeros((1 + maxlen, n_seqs, 256), device=dev, dtype=x3.dtype)
-                rows = x3[sel0[order].to(dev)]
-                x3_1_seq[(pos + 1).to(dev), seq_of_row.to(dev)] = rows
-                x3_1_mask = (torch.arange(1 + maxlen)[None, :] > counts[:, None]).to(dev)
-                lens = counts.to(torch.int32).to(dev)
-                x3_1b, att = self.aggregate(x3_1_seq[1:], lens, getatt)
+                x3_1_seq[plan["pos1"], plan["seq_of_row"]] = x3[plan["rows"]]
+                x3_1_mask = plan["mask"].clone()
+                x3_1b, att = self.aggregate(x3_1_seq[1:], plan["lens"], getatt)
                 if getatt:
                     attention_scores = [att[i, :int(c)].reshape(-1, 1) for i, c in enumerate(counts)]
             else:
