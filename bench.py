@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=T, help="frames of the clip the CPU baseline times")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a HIP graph (torch.cuda.CUDAGraph) and time graph replays")
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2",
                     help="c2 (default, the BASELINE metric's config): 10 x 800x800 frames, 32 ROI/frame, fp32; "
                          "c5: configs[4] per-GPU shape -- 30 x 1080x1920 frames, 64 ROI/frame (use with --dtype f16)")
@@ -129,17 +131,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    run = step
+    if args.graph:
+        # the whole step (about 130 launches of our kernels + torch glue) as ONE hipGraph: no allocation, no
+        # host sync and -- with the cached packing plan -- no H2D copy happens inside a steady-state step
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(cap):
+            step(); step()
+        torch.cuda.current_stream().wait_stream(cap)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            graph_out = step()
+        run = graph.replay
     log("warmup")
     with torch.no_grad():
         for _ in range(args.warmup):
-            step()
+            run()
             torch.cuda.synchronize()
             log("warmup step done")
         sync_all()
         log("timing")
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            run()
         sync_all()
         elapsed = time.perf_counter() - t0
     if world > 1:
@@ -195,7 +210,7 @@ def main():
                                        f" full pipeline, fixed ROIs: {T} frames {H}x{W} -> ResNet-50-FPN + RPN head "
                                        f"-> RoIAlign 14x14 ({R} ROI/frame) -> mask head -> match trunk x2 -> SEAM NLB + "
                                        f"attention pool ({R} seq x {T}) -> pair logits vs {G}-product bank -> top-{TOPK}",
-                           "clips_per_step_per_gpu": 1, "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
+                           "clips_per_step_per_gpu": 1, "hip_graph": bool(args.graph), "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
                            "algorithmic_tflop_per_clip": round(FLOP_PER_CLIP / 1e12, 3),
                            "parallelism": f"dp{world} (clips sharded; product bank all-gathered over RCCL)"
                            if world > 1 else "single GPU"},
