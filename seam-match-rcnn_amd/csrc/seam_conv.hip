@@ -148,9 +148,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
     // loads stay UNCONDITIONAL, the hardware returns zeros and nobody reads them.
     int uq = 0;
 
-    // Two register sets: the loads issued during chunk t are for chunk t+2 (a whole chunk of MFMAs
-    // of slack before they are written to LDS during chunk t+1).
-    f32x4 areg0[AI], breg0[BI], areg1[AI], breg1[BI];
+    // A ring of D register sets: the loads issued during chunk t are for chunk t+D, and are written to LDS
+    // during chunk t+D-1 -- D-1 chunks of MFMAs of slack.  fp32 chunks are long (64 MFMAs x 64 cycles per
+    // wave): D = 2 covers HBM latency; an fp16 chunk is only 16 MFMAs x 32 cycles, so it runs D = 3.
+    constexpr int D = F16 ? 3 : 2;
+    constexpr int P = F16 ? 6 : 2;               // unroll period = lcm(2 LDS buffers, D sets): all indices static
+    f32x4 areg[D][AI], breg[D][BI];
     auto load_a = [&](f32x4 (&ar)[AI], int i) {
         const bool ok = (unsigned)(ahi[i] + kr) < (unsigned)p.H && (unsigned)(awi[i] + ks) < (unsigned)p.W && kr < p.R;
         const unsigned off = ok ? (unsigned)(arow[i] + tapoff) : kOob;
@@ -259,16 +262,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
         for (int q = 0; q < Q; ++q) mf(fa1, fb1, q);
     };
 
-    load_chunk(areg0, breg0);                       // chunk 0
+    load_chunk(areg[0], breg[0]);                   // chunk 0 -> LDS buffer 0
 #pragma unroll
-    for (int r = 0; r < AI + BI; ++r) store_row(areg0, breg0, 0, r);
-    load_chunk(areg1, breg1);                       // chunk 1 stays in registers until chunk 0's k-slot 2
+    for (int r = 0; r < AI + BI; ++r) store_row(areg[0], breg[0], 0, r);
+#pragma unroll
+    for (int d = 1; d < D; ++d) load_chunk(areg[d], breg[d]);      // chunks 1..D-1 wait in registers
     __syncthreads();
     read_frags(fa0, fb0, 0, 0);
 
-    for (int t = 0; t < nk; t += 2) {
-        chunk(0, areg0, breg0, areg1, breg1);
-        if (t + 1 < nk) chunk(1, areg1, breg1, areg0, breg0);
+    // chunk t: LDS buffer t&1; loads of chunk t+D go to set t%D (its previous content, chunk t, is in LDS);
+    // set (t+1)%D (chunk t+1) is written to the other LDS buffer
+    for (int t = 0; t < nk; t += P) {
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+            if (t + u < nk) chunk(u & 1, areg[u % D], breg[u % D], areg[(u + 1) % D], breg[(u + 1) % D]);
     }
 
     // ---- epilogue: y = act(acc*scale + shift + residual) --------------------------------------
