@@ -190,6 +190,18 @@ int seam_match_scores_f32(const float* logits, float* score, int64_t n_pairs, se
 int seam_rank_of_f32(const float* logits, const int64_t* target, int64_t* rank, int Q, int G,
                      seam_stream_t stream);
 
+/* Rankings over per-frame score rows (evaluate_movingfashion.py:293-315): out[g] = mean (mode 0) or max
+ * (mode 1) over the n rows of score [n,G];  seam_rank_of_scores_f32: rank of target[q] in the descending
+ * order of the plain score row q of [Q,G] (ties -> lower index first; what `np.argsort(x)[::-1] ==
+ * shop_prod_index` extracts at :296-297,306-307). */
+int seam_score_reduce_f32(const float* score, float* out, int n, int G, int mode, seam_stream_t stream);
+int seam_rank_of_scores_f32(const float* score, const int64_t* target, int64_t* rank, int Q, int G,
+                            seam_stream_t stream);
+
+/* torchvision.ops.box_iou as the evaluator calls it to pick the tracklet that follows the ground truth
+ * (evaluate_movingfashion.py:205-209): a [Na,4], b [Nb,4] xyxy -> out [Na,Nb]. */
+int seam_box_iou_f32(const float* a, const float* b, float* out, int Na, int Nb, seam_stream_t stream);
+
 /* Fused pairwise logits + top-k (a13 + a14 in one pass; no [Q,G,2] round trip through HBM):
  * same ranking rule and bit-identical x1-x0 as seam_pair_logits_f32 + seam_rank_topk_f32.
  * k <= 256, k <= G; ws: >= seam_pair_topk_workspace_floats(Q,G,k) floats of scratch. */

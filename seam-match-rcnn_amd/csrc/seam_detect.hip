@@ -149,6 +149,19 @@ __global__ void paste_masks_kernel(const float* __restrict__ masks, const float*
     }
 }
 
+// torchvision.ops.box_iou (ref evaluate_movingfashion.py:207): iou[i,j] of xyxy boxes a[i], b[j]
+__global__ void box_iou_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int Na, int Nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Na * Nb) return;
+    const float4 p = reinterpret_cast<const float4*>(a)[i / Nb];
+    const float4 q = reinterpret_cast<const float4*>(b)[i % Nb];
+    const float ap = (p.z - p.x) * (p.w - p.y), aq = (q.z - q.x) * (q.w - q.y);
+    const float iw = fmaxf(fminf(p.z, q.z) - fmaxf(p.x, q.x), 0.f);
+    const float ih = fmaxf(fminf(p.w, q.w) - fmaxf(p.y, q.y), 0.f);
+    const float inter = iw * ih;
+    out[i] = inter / (ap + aq - inter);
+}
+
 }  // namespace
 
 extern "C" {
@@ -176,6 +189,12 @@ int seam_paste_masks_f32(const float* masks, const float* boxes, float* out, int
     int gx = (H * W + 255) / 256;
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(paste_masks_kernel, dim3(gx, K), dim3(256), 0, (hipStream_t)stream, masks, boxes, out, K, H, W);
+    return (int)hipGetLastError();
+}
+
+int seam_box_iou_f32(const float* a, const float* b, float* out, int Na, int Nb, void* stream) {
+    if (Na <= 0 || Nb <= 0) return 0;
+    hipLaunchKernelGGL(box_iou_kernel, dim3((Na * Nb + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, out, Na, Nb);
     return (int)hipGetLastError();
 }
 

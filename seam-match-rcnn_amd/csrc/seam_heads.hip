@@ -562,6 +562,43 @@ __global__ __launch_bounds__(256) void rank_of_kernel(const float* __restrict__ 
     if (tid == 0) rank[q] = (t >= 0 && t < G) ? (int64_t)(part[0] + part[1] + part[2] + part[3]) : (int64_t)-1;
 }
 
+// Column reduce of per-frame match scores [n,G] -> [G]: mode 0 = mean, 1 = max (the AVG / MAX DISTANCE
+// rankings, ref evaluate_movingfashion.py:293-296,305).
+__global__ void score_reduce_kernel(const float* __restrict__ s, float* __restrict__ out, int n, int G, int mode) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    float acc = mode ? -INFINITY : 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float v = s[(size_t)i * G + g];
+        acc = mode ? fmaxf(acc, v) : acc + v;
+    }
+    out[g] = mode ? acc : acc / (float)n;
+}
+
+// rank of target[q] in the descending order of a plain score row (ties -> lower index first)
+__global__ __launch_bounds__(256) void rank_of_scores_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
+                                                             int64_t* __restrict__ rank, int G) {
+    __shared__ int part[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* row = score + (size_t)q * G;
+    const int t = (int)target[q];
+    int cnt = 0;
+    if (t >= 0 && t < G) {
+        float dt = row[t];
+        if (dt != dt) dt = -INFINITY;
+        for (int g = tid; g < G; g += 256) {
+            float d = row[g];
+            if (d != d) d = -INFINITY;
+            cnt += (d > dt || (d == dt && g < t)) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) rank[q] = (t >= 0 && t < G) ? (int64_t)(part[0] + part[1] + part[2] + part[3]) : (int64_t)-1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -609,6 +646,19 @@ int seam_match_scores_f32(const float* logits, float* score, int64_t n_pairs, vo
 int seam_rank_of_f32(const float* logits, const int64_t* target, int64_t* rank, int Q, int G, void* stream) {
     if (Q <= 0) return 0;
     hipLaunchKernelGGL(rank_of_kernel, dim3(Q), dim3(256), 0, (hipStream_t)stream, logits, target, rank, G);
+    return (int)hipGetLastError();
+}
+
+int seam_score_reduce_f32(const float* score, float* out, int n, int G, int mode, void* stream) {
+    if (G <= 0) return 0;
+    if (n <= 0 || mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(score_reduce_kernel, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, score, out, n, G, mode);
+    return (int)hipGetLastError();
+}
+
+int seam_rank_of_scores_f32(const float* score, const int64_t* target, int64_t* rank, int Q, int G, void* stream) {
+    if (Q <= 0) return 0;
+    hipLaunchKernelGGL(rank_of_scores_kernel, dim3(Q), dim3(256), 0, (hipStream_t)stream, score, target, rank, G);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,263 @@
+"""Evaluator-side retrieval on the device in fp32.
+
+Counterpart of ``evaluate()`` in the reference's evaluate_movingfashion.py:15-445: descriptor collection
+(:26-80), the per-product tracking + the seven rankings (:157-334) and the accuracy tables (:338-445).
+The reference does this with NumPy fp16 matrices, a full ``argsort`` over the gallery per query and
+O(P^2) Python list scans on the CPU; here every arithmetic step is one kernel call on device-resident fp32
+tables and only the tiny per-product decisions (greedy tracklet linking over <= a few dozen boxes) run on
+the host:
+
+    compute_selfdist / compute_distances  -> seam_pair_logits_f32 + seam_match_scores_f32
+    compute_ranking(...) == shop_index    -> seam_rank_of_f32        (rank of the true product, no argsort)
+    AVG DESC mean / AVG,MAX DISTANCE      -> seam_score_reduce_f32 + seam_rank_of_scores_f32
+    AGGR DESC                             -> TemporalAggregationNLB Mode B (seam_nlb_attnpool_f32) + seam_rank_of_f32
+    box_iou                               -> seam_box_iou_f32
+
+Deliberate deviation: fp32 instead of the reference's fp16 tables (:82-92) -- SURVEY 8f f1 asks for it;
+tie rule "lower index first" instead of NumPy's unstable reversed argsort.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+
+K_THRESHOLDS = (1, 5, 10, 20)          # ref evaluate_movingfashion.py:15
+
+
+@dataclass
+class DescriptorTables:
+    """What evaluate_movingfashion.py:82-92 builds from the per-detection tuples; descriptor matrices live on
+    the device (fp32), the bookkeeping columns on the host."""
+    shop_mat: torch.Tensor              # [Ns,256] match_features of each product's shop box
+    shop_aggr: torch.Tensor             # [Ns,256] temporal_aggregator descriptor of the same box (:43-45)
+    shop_prods: np.ndarray              # [Ns] product index
+    shop_sources: np.ndarray            # [Ns] 1 = "regular", else "hard" (:216-219)
+    street_mat: torch.Tensor            # [Nq,256] match_features of every kept street detection
+    street_aggr: torch.Tensor           # [Nq,256] temporal_aggregator trunk descriptors (:73-78)
+    street_prods: np.ndarray            # [Nq]
+    street_imgs: np.ndarray             # [Nq] frame index inside its clip
+    street_scores: np.ndarray           # [Nq] detection confidence
+    street_boxes: torch.Tensor          # [Nq,4]
+    tracklets_gt: torch.Tensor          # [n,4] ground-truth boxes, indexed by frame index as the reference does (:205)
+    w: torch.Tensor                     # [2,256] match_predictor.last.weight
+    b: torch.Tensor                     # [2]
+    count_street: int = 0
+    product_keys: Optional[Sequence] = None
+
+
+@torch.no_grad()
+def collect_descriptors(model, data_loader, device, score_threshold: float = 0.0,
+                        first_n_withvideo: Optional[int] = None, step: int = 11) -> DescriptorTables:
+    """evaluate_movingfashion.py:26-92: run the model over (shop image, street frames...) batches, keep the
+    largest shop box and every street detection above the score threshold, plus their aggregator descriptors."""
+    agg = model.roi_heads.temporal_aggregator
+    shop_mat, shop_aggr, shop_prods, shop_src, keys = [], [], [], [], []
+    s_mat, s_aggr, s_prod, s_img, s_score, s_box, gts = [], [], [], [], [], [], []
+    w = b = None
+    count_products = count_street = 0
+    for images, targets in data_loader:
+        count_products += 1
+        images = [im.to(device) for im in images]
+        output = [o for x in range(0, len(images), step) for o in model(images[x:x + step])]
+        keep0 = output[0]["scores"] >= score_threshold
+        if not bool(keep0.any()):
+            continue
+        if w is None:
+            w, b = output[0]["w"].detach(), output[0]["b"].detach()
+        bs = output[0]["boxes"][keep0]
+        maxind = int(((bs[:, 2] - bs[:, 0]) * (bs[:, 3] - bs[:, 1])).argmax())
+        one_i = torch.ones(1, dtype=torch.int32)
+        shop_aggr.append(agg(output[0]["roi_features"][maxind].unsqueeze(0), one_i, torch.zeros(1, dtype=torch.int64))[1])
+        shop_mat.append(output[0]["match_features"][maxind].unsqueeze(0))
+        shop_prods.append(count_products - 1)
+        shop_src.append(int(targets[0].get("source", 1)))
+        keys.append(targets[0].get("i", count_products - 1))
+        gts += [torch.as_tensor(t["tracklet"], dtype=torch.float32).view(-1)[:4] for t in targets[1:]]
+        if first_n_withvideo is not None and count_products >= first_n_withvideo:
+            continue
+        count_street += 1
+        feats = []
+        for i, o in enumerate(output[1:]):
+            sel = (o["scores"] >= score_threshold).nonzero().view(-1)
+            if sel.numel() == 0:
+                continue
+            s_mat.append(o["match_features"][sel])
+            s_box.append(o["boxes"][sel])
+            s_score.append(o["scores"][sel])
+            s_prod += [count_products - 1] * sel.numel()
+            s_img += [i] * sel.numel()
+            feats.append(o["roi_features"][sel])
+        feats = torch.cat(feats, 0)
+        n = feats.shape[0]
+        seq = agg(feats, torch.zeros(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int64))[3][1:]
+        s_aggr.append(seq.reshape(-1, seq.shape[-1]))
+    return DescriptorTables(
+        shop_mat=torch.cat(shop_mat), shop_aggr=torch.cat(shop_aggr).reshape(len(shop_mat), -1),
+        shop_prods=np.asarray(shop_prods), shop_sources=np.asarray(shop_src),
+        street_mat=torch.cat(s_mat), street_aggr=torch.cat(s_aggr), street_prods=np.asarray(s_prod),
+        street_imgs=np.asarray(s_img), street_scores=torch.cat(s_score).cpu().numpy(), street_boxes=torch.cat(s_box),
+        tracklets_gt=torch.stack(gts).to(device) if gts else torch.zeros((0, 4), device=device),
+        w=w, b=b, count_street=count_street, product_keys=keys)
+
+
+def build_tracklets(simmat: np.ndarray, imgs: np.ndarray, scores: np.ndarray, threshold: float) -> List[List[int]]:
+    """Greedy tracklet linking of one product's detections (evaluate_movingfashion.py:166-202).
+
+    simmat [n,n] = compute_selfdist of the detections, imgs [n] their frame index, scores [n] the detection
+    confidences.  Repeatedly: seed a tracklet with the most confident unused detection; while frames without
+    a member remain, take the unused detection in such a frame with the highest similarity to ANY current
+    member; link it if that similarity exceeds ``threshold`` (it then closes its frame), else stop.
+    Returns tracklets as lists of LOCAL detection indices, in creation order."""
+    n = len(imgs)
+    free = np.ones(n, dtype=bool)
+    all_frames = np.unique(imgs)
+    tracks: List[List[int]] = []
+    while free.any():
+        cand = np.flatnonzero(free)
+        start = int(cand[np.argmax(scores[cand])])
+        members = [start]
+        open_frames = set(int(f) for f in all_frames if f != imgs[start])
+        while open_frames:
+            # `free` still holds the members of the tracklet under construction: they are only retired when it is
+            # closed, but their frames are closed, so they can never be picked again.
+            pool = np.asarray([j for j in range(n) if free[j] and int(imgs[j]) in open_frames], dtype=np.int64)
+            if pool.size == 0:
+                break
+            sub = simmat[np.sort(np.asarray(members))][:, pool]        # rows in detection order, like the reference
+            r, c = np.unravel_index(int(np.argmax(sub)), sub.shape)
+            if not sub[r, c] > threshold:
+                break
+            members.append(int(pool[c]))
+            open_frames -= {int(imgs[m]) for m in members}
+        free[members] = False
+        tracks.append(members)
+    return tracks
+
+
+@dataclass
+class RetrievalReport:
+    k_thresholds: Sequence[int]
+    counts: Dict[str, np.ndarray] = field(default_factory=dict)     # name -> hits per k threshold
+    count_street: int = 0
+    count_reg: int = 0
+    count_hard: int = 0
+    frames_per_product: int = 0
+    track_lens: List[int] = field(default_factory=list)
+    frame_ranks: List[int] = field(default_factory=list)            # all_ranks_list (:241)
+    per_product: Dict = field(default_factory=dict)                 # accs_per_product (:224,333-334)
+
+    def accuracy(self, name: str, subset: str = "") -> np.ndarray:
+        """The numbers the reference prints (:338-437): per-frame tables divide by #products x frames_per_product,
+        per-product tables by #products (of the subset)."""
+        n = {"": self.count_street, "_reg": self.count_reg, "_hard": self.count_hard}[subset]
+        denom = n * self.frames_per_product if name == "frame" else n
+        return self.counts[name + subset] / max(denom, 1)
+
+    def summary(self):
+        """(ret1, ret2, ret3) as ``evaluate`` returns them (:341,350,355,445)."""
+        return (float(self.accuracy("frame")[0]), float(self.accuracy("avg_desc")[0]), float(self.accuracy("aggr_desc")[0]))
+
+
+_TABLES = ("frame", "max_per_image", "aggr_desc", "avg_desc", "avg_dist", "max_dist", "max_score")
+
+
+@torch.no_grad()
+def evaluate_tables(t: DescriptorTables, temporal_aggregator, k_thresholds: Sequence[int] = K_THRESHOLDS,
+                    frames_per_product: int = 3, tracking_threshold: float = 0.3) -> RetrievalReport:
+    """evaluate_movingfashion.py:123-334 on device-resident tables."""
+    ks = np.asarray(k_thresholds)
+    rep = RetrievalReport(k_thresholds=tuple(k_thresholds), count_street=t.count_street, frames_per_product=frames_per_product)
+    for name in _TABLES:
+        for sub in ("", "_reg", "_hard"):
+            rep.counts[name + sub] = np.zeros(len(ks), dtype=np.int64)
+    dev = t.shop_mat.device
+    aggr_w, aggr_b = temporal_aggregator.last.weight.detach(), temporal_aggregator.last.bias.detach()
+
+    def hit(name, rank, sub):
+        h = (rank < ks).astype(np.int64)
+        rep.counts[name] += h
+        if name != "max_per_image":
+            rep.counts[name + sub] += h
+        return h
+
+    for p in range(t.count_street):
+        where = np.flatnonzero(t.shop_prods == p)
+        if where.size == 0:
+            continue
+        shop_index = int(where[0])
+        sub = "_reg" if t.shop_sources[shop_index] == 1 else "_hard"
+        if sub == "_reg":
+            rep.count_reg += 1
+        else:
+            rep.count_hard += 1
+        dets = np.flatnonzero(t.street_prods == p)
+        imgs, scores = t.street_imgs[dets], t.street_scores[dets]
+        dets_d = torch.as_tensor(dets, device=dev)
+        mine = t.street_mat[dets_d]
+
+        # ---- tracking (:166-214)
+        simmat = ops.match_scores(ops.pair_logits(mine, mine, t.w, t.b)).cpu().numpy()
+        tracks = build_tracklets(simmat, imgs, scores, tracking_threshold)
+        boxes = t.street_boxes[dets_d]
+        best, best_iou = 0, -np.inf
+        for ti, members in enumerate(tracks):
+            gt = t.tracklets_gt[torch.as_tensor(imgs[members], device=dev)]
+            iou = float(ops.box_iou(boxes[torch.as_tensor(members, device=dev)], gt).cpu().numpy().max(-1).sum())
+            if iou > best_iou:
+                best, best_iou = ti, iou
+        members = np.asarray(tracks[best])
+        rep.track_lens.append(len(members))
+        members = members[np.argsort(imgs[members], kind="stable")]          # frames visited in unique_imgs order (:225)
+
+        # ---- one query per tracked frame (:225-239)
+        m_d = torch.as_tensor(members, device=dev)
+        target = torch.full((len(members),), shop_index, dtype=torch.int64, device=dev)
+        logits = ops.pair_logits(mine[m_d], t.shop_mat, t.w, t.b)
+        frame_rank = ops.rank_of(logits, target).cpu().numpy()
+        distances = ops.match_scores(logits)                                     # [n_frames, G]
+        per = {"sfmr": np.zeros(len(ks)), "seamrcnn": np.zeros(len(ks))}
+        for r in frame_rank:
+            per["sfmr"] += hit("frame", r, sub)
+        rep.frame_ranks += [int(r) for r in frame_rank]
+        hit("max_per_image", frame_rank.min(), sub)                              # (:243-247)
+
+        # ---- AGGR DESC (:250-276): Mode B over the tracked frames' aggregator descriptors
+        seq = torch.zeros((1 + len(members), 1, t.street_aggr.shape[1]), device=dev)
+        seq[1:, 0] = t.street_aggr[dets_d[m_d]]
+        mask = torch.zeros((1, 1 + len(members)), dtype=torch.bool, device=dev)
+        desc = temporal_aggregator(None, None, None, x3_1_seq=seq, x3_1_mask=mask, x3_2=t.shop_aggr[shop_index:shop_index + 1])[0][:1]
+        r = int(ops.rank_of(ops.pair_logits(desc.contiguous(), t.shop_aggr, aggr_w, aggr_b), target[:1]).cpu())
+        per["seamrcnn"] += hit("aggr_desc", r, sub)
+
+        # ---- AVG DESC (:279-291)
+        avg = ops.score_reduce(mine[m_d].contiguous(), "mean").unsqueeze(0)
+        hit("avg_desc", int(ops.rank_of(ops.pair_logits(avg, t.shop_mat, t.w, t.b), target[:1]).cpu()), sub)
+
+        # ---- AVG & MAX DISTANCE (:293-315)
+        both = torch.stack([ops.score_reduce(distances, "mean"), ops.score_reduce(distances, "max")])
+        r2 = ops.rank_of_scores(both, target[:1].repeat(2)).cpu().numpy()
+        hit("avg_dist", int(r2[0]), sub)
+        hit("max_dist", int(r2[1]), sub)
+
+        # ---- MAX CONFIDENCE SCORE (:317-328)
+        hit("max_score", int(frame_rank[int(np.argmax(scores[members]))]), sub)
+
+        key = t.product_keys[shop_index] if t.product_keys is not None else shop_index
+        rep.per_product[key] = {"sfmr": per["sfmr"] / frames_per_product, "seamrcnn": per["seamrcnn"] / 1.0}
+    return rep
+
+
+@torch.no_grad()
+def evaluate(model, data_loader, device, score_threshold: float = 0.0, k_thresholds: Sequence[int] = K_THRESHOLDS,
+             frames_per_product: int = 3, tracking_threshold: float = 0.3, first_n_withvideo: Optional[int] = None,
+             return_report: bool = False):
+    """Same signature and return value (ret1, ret2, ret3) as the reference's ``evaluate``
+    (evaluate_movingfashion.py:15-16,445)."""
+    tables = collect_descriptors(model, data_loader, device, score_threshold, first_n_withvideo)
+    rep = evaluate_tables(tables, model.roi_heads.temporal_aggregator, k_thresholds, frames_per_product, tracking_threshold)
+    return (rep.summary(), rep) if return_report else rep.summary()

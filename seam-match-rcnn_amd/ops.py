@@ -343,6 +343,35 @@ def rank_of(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def score_reduce(score: torch.Tensor, mode: str) -> torch.Tensor:
+    """score [n,G] -> [G]: column mean (``"mean"``) or max (``"max"``)."""
+    score = _req(score)
+    n, g = score.shape
+    out = torch.empty((g,), dtype=F32, device=score.device)
+    _native.check(_native.lib().seam_score_reduce_f32(_ptr(score), _ptr(out), n, g, {"mean": 0, "max": 1}[mode], _stream()),
+                  "seam_score_reduce_f32")
+    return out
+
+
+def rank_of_scores(score: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """score [Q,G], target int64 [Q] -> rank int64 [Q] of the target in each row's descending order."""
+    score, target = _req(score), _req(target, torch.int64, "target")
+    q, g = score.shape
+    out = torch.empty((q,), dtype=torch.int64, device=score.device)
+    _native.check(_native.lib().seam_rank_of_scores_f32(_ptr(score), _ptr(target), _ptr(out), q, g, _stream()),
+                  "seam_rank_of_scores_f32")
+    return out
+
+
+def box_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """xyxy boxes a [Na,4], b [Nb,4] -> IoU [Na,Nb]."""
+    a, b = _req(a), _req(b)
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=F32, device=a.device)
+    _native.check(_native.lib().seam_box_iou_f32(_ptr(a), _ptr(b), _ptr(out), a.shape[0], b.shape[0], _stream()),
+                  "seam_box_iou_f32")
+    return out
+
+
 def pair_topk(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, k: int, fused: bool = False,
               q_chunk: int = 64):
     """a13+a14 without materialising the full [Q,G,2] logits -> (idx int64 [Q,k], score [Q,k]).
