@@ -49,7 +49,8 @@ const char* seam_error_string(int code);
  *          [n_tile][chunk][BN][32]; opaque to the caller)
  * scale    [K] or NULL (=1);  shift [K] or NULL (=0)   (bias / folded BatchNorm)
  * residual NHWC [N,Ho,Wo,K] or NULL, added before the activation
- * relu     0/1
+ * relu     0 none | 1 ReLU | 2 (backward passes) `residual` is NOT added: the result is zeroed where
+ *          residual <= 0 -- the ReLU mask of the forward activation fused into the input-gradient conv
  * kred     padded reduction length = seam_conv_kred(C,R,S)
  */
 int seam_conv_kred(int C, int R, int S);           /* host helper: ceil(R*S*C / 32) * 32 */
@@ -61,7 +62,11 @@ int seam_conv_tile(int M, int K);                  /* host helper: BM*1000+BN of
  * (rows_padded*kred floats; reduction chunks ordered (r, c-chunk, s); channels >= Cin zero-filled).
  * mode 0: Conv2d / Linear (Linear = R=S=1; fc6 = a 7x7 "valid" conv over the 7x7 ROI tile)
  * mode 1: ConvTranspose2d(k=2,s=2) weight [Cin,Cout,2,2] -> rows ((a*2+b)*Cout + co),
- *         i.e. a 1x1 conv producing the 4 sub-pixels as channel groups; K = 4*Cout.   */
+ *         i.e. a 1x1 conv producing the 4 sub-pixels as channel groups; K = 4*Cout.
+ * mode 2: input-gradient weights of a Conv2d whose OIHW weight is w [Cin, K, R, S] (note the roles:
+ *         K = the forward conv's INPUT channels = rows produced, Cin = its output channels = channels
+ *         reduced): taps rotated by 180 degrees, channels swapped, so that
+ *         dX = seam_conv2d_f32(dY, packed, pad = R-1-pad_fwd) for a stride-1 conv (Linear: W^T).   */
 int seam_pack_conv_weight_f32(const float* w, float* w_packed, int K, int Cin, int R, int S,
                               int Cstore, int mode, seam_stream_t stream);
 
@@ -238,6 +243,58 @@ int seam_mask_select_f32(const float* logits, const int64_t* labels, float* prob
 
 int seam_mask_select_f16(const void* logits, const int64_t* labels, float* prob, int K, int ncls,
                          seam_stream_t stream);   /* fp16 logits in, fp32 probabilities out */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Gradient kernels of the match heads: the grad-enabled pass of the training loop,
+ * stuffs/engine.py:120-121,158-168,183-185 -> MatchPredictor / TemporalAggregationNLB in .train()
+ * (models/match_head.py:66-76,90-169,339).  fp32, fixed-order reductions (bit-reproducible).
+ *
+ * seam_conv_wgrad_f32: dw [K,C,R,S] (OIHW) = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,ho*stride+r-pad,wo*stride+s-pad,c]
+ *   for x NHWC [N,H,W,C], dy NHWC [N,Ho,Wo,K]; C,K multiples of 4.  fp32-MFMA GEMM split over the pixel
+ *   axis; ws: >= seam_conv_wgrad_workspace_floats(M = N*Ho*Wo, C, K, R, S) floats.  (Linear: R=S=1, H=W=1.)
+ * seam_colsum_f32: out[k] = sum_m x[m,k]  (bias gradients). */
+int64_t seam_conv_wgrad_workspace_floats(int M, int C, int K, int R, int S);
+int seam_conv_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K,
+                        int R, int S, int stride, int pad, float* ws, seam_stream_t stream);
+int seam_colsum_f32(const float* x, float* out, int M, int K, seam_stream_t stream);
+
+/* Backward of conv_seq's last ReLU -> AvgPool2d(6,6) -> ReLU (models/match_head.py:56-60):
+ * dy[n,hw,c] = y[n,hw,c] > 0 ? dpool[n,c] / HW : 0   (y = the ReLU'd conv output, NHWC [N,HW,C]). */
+int seam_avgpool_relu_bwd_f32(const float* dpool, const float* y, float* dy, int N, int HW, int C,
+                              seam_stream_t stream);
+
+/* nn.BatchNorm1d(256) in training mode (models/match_head.py:62): batch statistics over the M rows (M >= 2),
+ * running_mean/var updated in place with `momentum` (unbiased variance), or left alone when NULL;
+ * save_mean / save_invstd [F] feed seam_bn1d_bwd_f32 (dx, dgamma, dbeta). */
+int seam_bn1d_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                            float* save_mean, float* save_invstd, float* running_mean,
+                            float* running_var, int M, int F, float momentum, float eps,
+                            seam_stream_t stream);
+int seam_bn1d_bwd_f32(const float* dy, const float* x, const float* save_mean, const float* save_invstd,
+                      const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int F,
+                      int frozen /* 1: eval-mode statistics, dx = gamma*invstd*dy */, seam_stream_t stream);
+
+/* nn.CrossEntropyLoss(weight=[w0,w1]) over [n,2] logits with int64 targets, mean reduction -- the criterion of
+ * every loss of models/match_head.py (:213,257,367,386): loss [1] and dloss/dlogits [n,2] in one launch. */
+int seam_ce2_fwd_bwd_f32(const float* logits, const int64_t* target, const float* weight, float* loss,
+                         float* dlogits, int64_t n, seam_stream_t stream);
+
+/* Gradients of seam_pair_logits_f32: g [Q,G,2] -> da [Q,256], db [G,256], dw [2,256], dbias [2]. */
+int seam_pair_logits_bwd_f32(const float* a, const float* b, const float* w, const float* g, float* da,
+                             float* db, float* dw, float* dbias, int Q, int G, int D,
+                             seam_stream_t stream);
+
+/* Gradients of seam_nlb_attnpool_f32 (same operand layouts; Tmax <= 64): dout [S,256] -> dseq (same strides
+ * as seq; only rows t < len[s] are written) and the parameter gradients, grads[11] = device pointers in the
+ * reference's layouts: theta.weight [128,256], theta.bias [128], phi.weight, phi.bias, g.weight, g.bias,
+ * concat_project.0.weight [256], W.weight [256,128], W.bias [256], attention_scorer.weight [256], .bias [1].
+ * ws: >= seam_nlb_bwd_workspace_floats(S,Tmax) floats. */
+int64_t seam_nlb_bwd_workspace_floats(int S, int Tmax);
+int seam_nlb_attnpool_bwd_f32(const float* seq, int64_t t_stride, int64_t s_stride, const int* len, int S,
+                              int Tmax, const float* w_proj_t, const float* b_proj, const float* w_cat,
+                              const float* w_out_t, const float* b_out, const float* w_att,
+                              const float* b_att, const float* dout, float* dseq, float* const* grads,
+                              float* ws, int use_nlb, seam_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -19,18 +19,19 @@ import torch.nn.functional as F
 BN_EPS = 1e-5   # nn.BatchNorm1d default (ref models/match_head.py:62)
 
 
-def match_trunk(x: torch.Tensor, p: dict) -> torch.Tensor:
+def match_trunk(x: torch.Tensor, p: dict, bn_train: bool = False) -> torch.Tensor:
     """``conv_seq -> pool -> linear`` : [K,256,14,14] -> x3[K,256].
 
     ref models/match_head.py:50-62 (ctor), :67-69 / :93-95 (forward).
     Four *valid* 3x3 convs + ReLU (14->12->10->8->6), AvgPool 6x6, (no-op) ReLU,
-    Linear 1024->256, BatchNorm1d in eval mode (running statistics)."""
+    Linear 1024->256, BatchNorm1d: eval mode = running statistics; ``bn_train`` = what the module does in
+    ``.train()`` (batch statistics, running buffers in ``p`` updated in place with momentum 0.1)."""
     for i in (0, 2, 4, 6):
         x = F.relu(F.conv2d(x, p[f"conv_seq.{i}.weight"], p[f"conv_seq.{i}.bias"]))
     x = F.relu(F.avg_pool2d(x, (6, 6)))
     x = F.linear(x.flatten(1), p["linear.0.weight"], p["linear.0.bias"])
     x = F.batch_norm(x, p["linear.1.running_mean"], p["linear.1.running_var"],
-                     p["linear.1.weight"], p["linear.1.bias"], False, 0.0, BN_EPS)
+                     p["linear.1.weight"], p["linear.1.bias"], bn_train, 0.1 if bn_train else 0.0, BN_EPS)
     return x
 
 
@@ -48,9 +49,9 @@ def pair_logits(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, bias: torch.T
     return out
 
 
-def match_predictor_forward(x, types, p):
+def match_predictor_forward(x, types, p, bn_train: bool = False):
     """``MatchPredictor.forward(x, types) -> (x3, x5)``; ref models/match_head.py:66-76."""
-    x3 = match_trunk(x, p)
+    x3 = match_trunk(x, p, bn_train)
     t = torch.as_tensor(types)
     x5 = pair_logits(x3[t == 0], x3[t == 1], p["last.weight"], p["last.bias"])
     return x3, x5
@@ -129,11 +130,11 @@ def unpack_sequences(x3_1_seq: torch.Tensor, x3_1_mask: torch.Tensor):
 
 
 def temporal_aggregation_forward(x, types, ids, p, x3_1_seq=None, x3_1_mask=None, x3_2=None,
-                                 getatt=False):
+                                 getatt=False, bn_train: bool = False):
     """``TemporalAggregationNLB.forward``; ref models/match_head.py:90-169 (both modes)."""
     atts = None
     if x3_1_seq is None:
-        x3 = match_trunk(x, p)
+        x3 = match_trunk(x, p, bn_train)
         t = torch.as_tensor(types)
         idt = torch.as_tensor(ids)
         x3_1 = x3[t == 0]

@@ -65,6 +65,16 @@ SIGNATURES = {
     "seam_nms_sorted_f32": (_i, [_p, _p, _i, _i, _f, _p, _p]),
     "seam_paste_masks_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "seam_mask_select_f32": (_i, [_p, _p, _p, _i, _i, _p]),
+    "seam_conv_wgrad_workspace_floats": (_i64, [_i, _i, _i, _i, _i]),
+    "seam_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "seam_colsum_f32": (_i, [_p, _p, _i, _i, _p]),
+    "seam_avgpool_relu_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "seam_bn1d_train_fwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _p]),
+    "seam_bn1d_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "seam_ce2_fwd_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
+    "seam_pair_logits_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "seam_nlb_bwd_workspace_floats": (_i64, [_i, _i]),
+    "seam_nlb_attnpool_bwd_f32": (_i, [_p, _i64, _i64, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), _p, _i, _p]),
 }
 
 _lib = None

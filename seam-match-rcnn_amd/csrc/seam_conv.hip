@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r] * sc + sh;
-                if (p.res) v += rv[r];
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.res) v = p.relu == 2 ? (rv[r] > 0.f ? v : 0.f) : v + rv[r];    // relu 2: ReLU mask of `res` (backward)
+                if (p.relu == 1) v = fmaxf(v, 0.f);
                 if constexpr (F16) {
                     if (p.y_f32) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, nok ? eo[r] * 4u : kOob, 0, 0);
@@ -372,6 +372,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
         if (row < K && c < Cin && r < R) {
             if (mode == 0) {
                 v = w[(((size_t)row * Cin + c) * R + r) * S + s2];
+            } else if (mode == 2) {   // input-gradient weights of a Conv2d [Cin(out), K(in), R, S]: rotate 180, swap channels
+                v = w[(((size_t)c * K + row) * R + (R - 1 - r)) * S + (S - 1 - s2)];
             } else {  // ConvTranspose2d weight [Cin, Cout, 2, 2]; row = (a*2+b)*Cout + co
                 const int cout = K / 4;
                 const int ab = row / cout;

@@ -13,7 +13,10 @@ losses of the reference file are callers of these heads, not part of the forward
 Arithmetic: trunk = 4 valid 3x3 implicit-GEMM convs + avg-pool + Linear/BatchNorm epilogue
 (``seam_conv2d_f32``), sequences -> one batched NLB+attention-pool launch
 (``seam_nlb_attnpool_f32``), pairwise classifier (``seam_pair_logits_f32``).  No CPU or
-eager fallback: CPU tensors / autograd raise.
+eager fallback: CPU tensors raise.  In ``.train()`` / with autograd on (the grad-enabled pass of
+``stuffs/engine.py:158-168``) the same stages run as ``autograd.py`` nodes whose backward is
+``csrc/seam_backward.hip``; the reference's losses (``models/losses.py``) are re-exported
+here because ``stuffs/engine.py:11-12`` imports them from this module.
 """
 from __future__ import annotations
 
@@ -24,13 +27,16 @@ from .. import ops
 from .nlb import NONLocalBlock1D
 
 
-def _no_grad_guard(module: nn.Module, *tensors):
-    if torch.is_grad_enabled() and (module.training or any(t is not None and t.requires_grad for t in tensors)):
-        if any(p.requires_grad for p in module.parameters()) or any(
-                t is not None and t.requires_grad for t in tensors):
-            raise NotImplementedError(
-                "the HIP path is forward/inference only: call under torch.no_grad() with the module in "
-                "eval() (backward kernels + BatchNorm1d train mode are SURVEY.md 8f row f2, not built)")
+def _wants_tape(module: nn.Module, *tensors) -> bool:
+    """True when the call must go through the autograd bridges (``autograd.py``): BatchNorm1d in training mode
+    (batch statistics, even under no_grad), or grad mode with something that requires grad -- the grad-enabled
+    pass of the training loop, ref stuffs/engine.py:120-121,158-168."""
+    if module.linear[1].training:
+        return True
+    if not torch.is_grad_enabled():
+        return False
+    return any(p.requires_grad for p in module.parameters()) or any(
+        t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
 
 
 def pack_nlb_from_state(sd: dict, prefix: str = "") -> ops.PackedNLB:
@@ -134,16 +140,39 @@ class MatchPredictor(nn.Module):
 
     def trunk(self, x: torch.Tensor) -> torch.Tensor:
         """x NCHW [K,256,14,14] (the reference's layout) -> x3 [K,256]."""
-        if self.linear[1].training and torch.is_grad_enabled():
-            raise NotImplementedError("BatchNorm1d train mode / autograd is not built (SURVEY.md 8f row f2)")
+        if _wants_tape(self, x):
+            return self.trunk_taped(x)
         return self.trunk_nhwc(ops.nchw_to_nhwc(x.detach().to(torch.float32), getattr(self, "compute_dtype", torch.float32)))
+
+    def trunk_taped(self, x: torch.Tensor) -> torch.Tensor:
+        """The trunk as ONE autograd node (fp32): forward kernels + BatchNorm1d batch statistics when the BN layer
+        is in training mode; backward = csrc/seam_backward.hip.  Mirrors nn.BatchNorm1d's buffer updates."""
+        from ..autograd import TrunkFunction
+        bn = self.linear[1]
+        if not x.is_cuda:
+            raise ops._native.SeamNativeError("x: expected a tensor on the HIP device (no CPU path exists)")
+        bn_train = bn.training or bn.running_mean is None
+        momentum = 0.0
+        if bn_train and bn.track_running_stats and bn.running_mean is not None:
+            bn.num_batches_tracked += 1
+            momentum = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+        c = self.conv_seq
+        rm = bn.running_mean if bn.track_running_stats else None
+        rv = bn.running_var if bn.track_running_stats else None
+        if not bn_train and rm is None:
+            raise NotImplementedError("BatchNorm1d without running statistics in eval mode")
+        return TrunkFunction.apply(x, c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[4].weight, c[4].bias,
+                                   c[6].weight, c[6].bias, self.linear[0].weight, self.linear[0].bias, bn.weight, bn.bias,
+                                   rm, rv, bn_train, momentum, bn.eps)
 
     def pair(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         """x5 = last((a_i - b_j)^2): [Q,256] x [G,256] -> [Q,G,2]   (ref :73-74, :161-162)."""
+        if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad or self.last.weight.requires_grad):
+            from ..autograd import PairLogitsFunction
+            return PairLogitsFunction.apply(a, b, self.last.weight, self.last.bias)
         return ops.pair_logits(a, b, self.last.weight, self.last.bias)
 
     def forward(self, x, types):
-        _no_grad_guard(self, x)
         x3 = self.trunk(x)
         types = torch.as_tensor(types).to(x3.device)       # callers pass a CPU IntTensor (video_matchrcnn.py:307)
         x5 = self.pair(x3[types == 0], x3[types == 1])
@@ -164,11 +193,22 @@ class TemporalAggregationNLB(MatchPredictor):
         """seq_tm: time-major [T,S,256] (rows >= len[s] ignored); lens int32 [S] on device."""
         t, s = seq_tm.shape[0], seq_tm.shape[1]
         pk = self.newnlb.packed(self.attention_scorer)
+        n = self.newnlb
+        params = (n.theta.weight, n.theta.bias, n.phi.weight, n.phi.bias, n.g.weight, n.g.bias, n.concat_project[0].weight,
+                  n.W.weight, n.W.bias, self.attention_scorer.weight, self.attention_scorer.bias)
+        if torch.is_grad_enabled() and (seq_tm.requires_grad or any(p.requires_grad for p in params)):
+            from ..autograd import NlbAttnPoolFunction
+            out = NlbAttnPoolFunction.apply(seq_tm, lens, 1 if self.nlb else 0, *params)
+            att = None
+            if want_att:
+                with torch.no_grad():
+                    _, att = ops.nlb_attnpool(seq_tm.detach(), s * 256, 256, lens, s, t, pk, use_nlb=1 if self.nlb else 0,
+                                              want_att=True)
+            return out, att
         return ops.nlb_attnpool(seq_tm, s * 256, 256, lens, s, t, pk, use_nlb=1 if self.nlb else 0,
                                 want_att=want_att)
 
     def forward(self, x, types, ids, x3_1_seq=None, x3_1_mask=None, x3_2=None, getatt=False):
-        _no_grad_guard(self, x, x3_1_seq, x3_2)
         attention_scores = None
         if x3_1_seq is None:
             # ---------------- Mode A: raw ROI features (ref :92-132) ----------------
@@ -199,12 +239,14 @@ class TemporalAggregationNLB(MatchPredictor):
             m = x3_1_mask.to(dev)
             first = torch.where(m.any(1), m.to(torch.int32).argmax(1), torch.full((n_seqs,), tp1, device=dev))
             lens = (first - 1).clamp(min=0).to(torch.int32)             # slice 1:first_masked (ref :136-139)
-            seq = x3_1_seq.detach().to(torch.float32).contiguous()
+            seq = x3_1_seq.to(torch.float32).contiguous()
             x3_1b, att = self.aggregate(seq[1:], lens, getatt)
             if getatt:
                 lc = lens.cpu().tolist()
                 attention_scores = [att[i, :n].reshape(-1, 1) for i, n in enumerate(lc)]
-            x3_2 = x3_2.detach().to(torch.float32)
+            x3_2 = x3_2.to(torch.float32)
+            if x3_2.dim() == 1:
+                x3_2 = x3_2[None]
             x3_1_ids = torch.zeros((1, 2))      # just to have numel > 0 (ref :158)
 
         x5 = self.pair(x3_1b, x3_2) if x3_1b is not None else None
@@ -214,3 +256,8 @@ class TemporalAggregationNLB(MatchPredictor):
 
 
 TemporalAggregation = TemporalAggregationNLB
+
+
+# the loss classes the reference's training loops import from this module (ref stuffs/engine.py:11-12)
+from .losses import (AggregationMatchLossDF2, MatchLossDF2, MatchLossWeak,          # noqa: E402,F401
+                     NEWBalancedAggregationMatchLossWeak)

@@ -115,6 +115,128 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
     return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype)
 
 
+def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0) -> PackedConv:
+    """Weights of the INPUT-GRADIENT conv of a stride-1 Conv2d / Linear with OIHW weight [Cout,Cin,R,S]:
+    dX = conv2d(dY, pack_conv_dgrad(W))  (taps rotated 180 degrees, channels swapped, pad R-1-pad_fwd)."""
+    lib = _native.lib()
+    weight = _req(weight.detach(), name="weight")
+    if weight.dim() == 2:
+        weight = weight[:, :, None, None]
+    weight = weight.contiguous()
+    cout, cin, R, S = weight.shape
+    if cout % 32 or R != S:
+        raise ValueError("pack_conv_dgrad: Cout must be a multiple of 32 and the kernel square")
+    rows = lib.seam_conv_rows_padded(cin)
+    kred = lib.seam_conv_kred(cout, R, S)
+    wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
+    _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), cin, cout, R, S, cout, 2, _stream()),
+                  "seam_pack_conv_weight_f32")
+    return PackedConv(wp, None, None, cin, cout, R, S, 1, R - 1 - pad_fwd, cout, F32)
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int = 1, pad: int = 0) -> torch.Tensor:
+    """x NHWC [N,H,W,C], dy NHWC [N,Ho,Wo,K] -> dW in PyTorch OIHW layout [K,C,R,S] (fp32 MFMA, split over pixels)."""
+    lib = _native.lib()
+    x, dy = _req(x, name="x"), _req(dy, name="dy")
+    n, h, w, c = x.shape
+    k = dy.shape[-1]
+    m = dy.numel() // k
+    dw = torch.empty((k, c, R, S), dtype=F32, device=x.device)
+    ws = torch.empty((int(lib.seam_conv_wgrad_workspace_floats(m, c, k, R, S)),), dtype=F32, device=x.device)
+    _native.check(lib.seam_conv_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), n, h, w, c, k, R, S, stride, pad, _ptr(ws), _stream()),
+                  "seam_conv_wgrad_f32")
+    return dw
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """[..., K] -> [K] sum over all leading dims (bias gradients)."""
+    x = _req(x)
+    k = x.shape[-1]
+    out = torch.empty((k,), dtype=F32, device=x.device)
+    _native.check(_native.lib().seam_colsum_f32(_ptr(x), _ptr(out), x.numel() // k, k, _stream()), "seam_colsum_f32")
+    return out
+
+
+def avgpool_relu_bwd(dpool: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """dpool [N,C], y NHWC [N,H,W,C] (post-ReLU conv output) -> dy [N,H,W,C]."""
+    dpool, y = _req(dpool), _req(y)
+    n, h, w, c = y.shape
+    dy = torch.empty_like(y)
+    _native.check(_native.lib().seam_avgpool_relu_bwd_f32(_ptr(dpool), _ptr(y), _ptr(dy), n, h * w, c, _stream()),
+                  "seam_avgpool_relu_bwd_f32")
+    return dy
+
+
+def bn1d_train_fwd(x, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    """BatchNorm1d with batch statistics; running buffers (or None) updated in place -> (y, save_mean, save_invstd)."""
+    x = _req(x)
+    m, f = x.shape
+    if m < 2:
+        raise ValueError("Expected more than 1 value per channel when training, got input size " + str(tuple(x.shape)))
+    y = torch.empty_like(x)
+    mean = torch.empty((f,), dtype=F32, device=x.device)
+    inv = torch.empty((f,), dtype=F32, device=x.device)
+    _native.check(_native.lib().seam_bn1d_train_fwd_f32(_ptr(x), _ptr(_req(gamma.detach())), _ptr(_req(beta.detach())), _ptr(y),
+                                                        _ptr(mean), _ptr(inv), _ptr(running_mean), _ptr(running_var), m, f,
+                                                        float(momentum), float(eps), _stream()), "seam_bn1d_train_fwd_f32")
+    return y, mean, inv
+
+
+def ce2_fwd_bwd(logits: torch.Tensor, target: torch.Tensor, weight: torch.Tensor):
+    """Weighted 2-class cross entropy (mean): logits [n,2], target int64 [n], weight [2] -> (loss [], dlogits [n,2])."""
+    logits = _req(logits)
+    target = _req(target.to(logits.device), torch.int64, "target")
+    weight = _req(weight.to(logits.device))
+    loss = torch.empty((), dtype=F32, device=logits.device)
+    dl = torch.empty_like(logits)
+    _native.check(_native.lib().seam_ce2_fwd_bwd_f32(_ptr(logits), _ptr(target), _ptr(weight), _ptr(loss), _ptr(dl),
+                                                     logits.shape[0], _stream()), "seam_ce2_fwd_bwd_f32")
+    return loss, dl
+
+
+def bn1d_bwd(dy, x, save_mean, save_invstd, gamma, frozen: bool = False):
+    dy, x = _req(dy), _req(x)
+    m, f = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty((f,), dtype=F32, device=x.device)
+    db = torch.empty((f,), dtype=F32, device=x.device)
+    _native.check(_native.lib().seam_bn1d_bwd_f32(_ptr(dy), _ptr(x), _ptr(save_mean), _ptr(save_invstd), _ptr(_req(gamma.detach())),
+                                                  _ptr(dx), _ptr(dg), _ptr(db), m, f, int(frozen), _stream()), "seam_bn1d_bwd_f32")
+    return dx, dg, db
+
+
+def pair_logits_bwd(a, b, w, g):
+    """Gradients of ``pair_logits``: g [Q,G,2] -> (da [Q,256], db [G,256], dw [2,256], dbias [2])."""
+    a, b, w, g = _req(a), _req(b), _req(w.detach()), _req(g)
+    q, gg, d = a.shape[0], b.shape[0], a.shape[1]
+    da, db = torch.zeros_like(a), torch.zeros_like(b)
+    dw = torch.zeros((2, d), dtype=F32, device=a.device)
+    dbias = torch.zeros((2,), dtype=F32, device=a.device)
+    if q and gg:
+        _native.check(_native.lib().seam_pair_logits_bwd_f32(_ptr(a), _ptr(b), _ptr(w), _ptr(g), _ptr(da), _ptr(db), _ptr(dw),
+                                                             _ptr(dbias), q, gg, d, _stream()), "seam_pair_logits_bwd_f32")
+    return da, db, dw, dbias
+
+
+def nlb_attnpool_bwd(seq, t_stride, s_stride, lens, n_seq, t_max, pk: "PackedNLB", dout, use_nlb=1):
+    """Gradients of ``nlb_attnpool``: dout [S,256] -> (dseq like seq, [11 parameter gradients in the reference's layouts:
+    theta.w, theta.b, phi.w, phi.b, g.w, g.b, concat_project.w, W.w, W.b, attention_scorer.w, attention_scorer.b])."""
+    lib = _native.lib()
+    seq, dout = _req(seq, name="seq"), _req(dout, name="dout")
+    dev = seq.device
+    dseq = torch.zeros_like(seq)
+    shapes = [(128, 256, 1), (128,), (128, 256, 1), (128,), (128, 256, 1), (128,), (1, 256, 1, 1), (256, 128, 1), (256,), (1, 256), (1,)]
+    grads = [torch.zeros(sh, dtype=F32, device=dev) for sh in shapes]
+    if n_seq:
+        ws = torch.empty((int(lib.seam_nlb_bwd_workspace_floats(n_seq, t_max)),), dtype=F32, device=dev)
+        arr = (C.c_void_p * 11)(*[g.data_ptr() for g in grads])
+        _native.check(lib.seam_nlb_attnpool_bwd_f32(_ptr(seq), t_stride, s_stride, _ptr(_req(lens, torch.int32, "lens")), n_seq, t_max,
+                                                    _ptr(pk.w_proj_t), _ptr(pk.b_proj), _ptr(pk.w_cat), _ptr(pk.w_out_t),
+                                                    _ptr(pk.b_out), _ptr(pk.w_att), _ptr(pk.b_att), _ptr(dout), _ptr(dseq), arr,
+                                                    _ptr(ws), int(use_nlb), _stream()), "seam_nlb_attnpool_bwd_f32")
+    return dseq, grads
+
+
 def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
     """NHWC implicit-GEMM conv (+scale/shift, +residual, +ReLU) -> NHWC [N,Ho,Wo,K].
@@ -140,7 +262,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     lib = _native.lib()
     if pc.dtype == F32:
         _native.check(lib.seam_conv2d_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
-                                          n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, 1 if relu else 0, _stream()),
+                                          n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, int(relu), _stream()),
                       "seam_conv2d_f32")
     else:
         _native.check(lib.seam_conv2d_f16(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),

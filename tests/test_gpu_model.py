@@ -78,15 +78,15 @@ def test_nlb_module_golden(heads, golden):
         assert_close(z, torch.from_numpy(golden[f"nlb_T{t}_z"]))
 
 
-def test_heads_refuse_training_and_cpu(heads):
+def test_heads_refuse_cpu_tensors(heads):
     mp, ta = heads
     x = torch.from_numpy(synth.roi_features(31, 2))
     with pytest.raises(Exception):
         mp(x, torch.IntTensor([0, 1]))                     # CPU tensor: no fallback
     mp.train()
     try:
-        with pytest.raises(NotImplementedError):
-            mp(x.to(dev()), torch.IntTensor([0, 1]))       # grad-enabled training pass: not built (row f2)
+        with pytest.raises(Exception):
+            mp(x, torch.IntTensor([0, 1]))                 # ... in train mode either (tests/test_gpu_train.py covers row f2)
     finally:
         mp.eval()
 

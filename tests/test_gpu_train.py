@@ -1,0 +1,259 @@
+"""GPU parity of the gradient kernels and of the grad-enabled pass of the heads: HIP backward
+through the C ABI vs torch-CPU autograd over the oracle, and vs the fixture captured from the reference's own
+modules + losses in train mode."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import seam_match_rcnn_amd.synth as synth
+from conftest import ROOT, to_torch
+from oracle import heads as OH
+from oracle import losses as OL
+from test_train_oracle import check_grads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+# gradients that are analytically ZERO (both sides hold rounding noise only): a bias in front of a batch-statistics
+# BatchNorm, and the attention scorer's bias (softmax is shift invariant)
+ZERO_BN_TRAIN = ("linear.0.bias",)
+ZERO_ALWAYS = ("attention_scorer.bias",)
+
+
+# A ReLU whose pre-activation is ~1e-7 on one side and exactly 0 on the other FLIPS its backward mask between two
+# correct fp32 forwards with different summation orders (measured: 1-2 such elements out of ~1.5 M per step,
+# tools/train_grad_check.py).  One flipped element moves the conv-trunk gradients by ~1e-3 in relative L2 (it is one of
+# ~2.4e5 active terms) while every other parameter still agrees to ~2e-5, so the conv_seq gradients of whole training
+# steps are compared by relative L2 norm; the kernels themselves are checked element-wise above.
+L2_KEYS = ("conv_seq",)
+
+
+def close(got, want, rtol=2e-4, atol_frac=2e-5, msg="", zero=(), l2=()):
+    got, want = got.detach().cpu().numpy(), want.detach().cpu().numpy()
+    assert got.shape == want.shape, (got.shape, want.shape, msg)
+    if any(z in msg for z in l2):
+        assert float(np.linalg.norm(got - want) / np.linalg.norm(want)) < 5e-3, msg
+        return
+    if any(msg.endswith(z) for z in zero):
+        assert float(np.abs(got).max()) < 1e-4 and float(np.abs(want).max()) < 1e-4, msg
+        return
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol_frac * (float(np.abs(want).max()) + 1e-30) + 1e-9, err_msg=msg)
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy(synth.normal(synth.stream_id(seed, "t"), shape) * np.float32(scale))
+
+
+@pytest.mark.parametrize("n,h,w,c,k,r,stride,pad", [
+    (5, 14, 14, 256, 256, 3, 1, 0), (3, 8, 8, 256, 1024, 3, 1, 0), (7, 1, 1, 1024, 256, 1, 1, 0),
+    (2, 9, 11, 32, 64, 3, 1, 1), (2, 10, 7, 36, 20, 3, 2, 1), (40, 6, 6, 128, 132, 1, 1, 0)])
+def test_conv_wgrad_and_dgrad(n, h, w, c, k, r, stride, pad):
+    from seam_match_rcnn_amd import ops
+    x = rnd(1, n, c, h, w).requires_grad_(True)
+    wt = rnd(2, k, c, r, r, scale=0.05).requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride, pad)
+    dy = rnd(3, *y.shape)
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw = ops.conv_wgrad(xd, dyd, r, r, stride, pad)
+    close(dw, wt.grad, msg="wgrad")
+    close(ops.colsum(dyd), dy.sum((0, 2, 3)), msg="colsum")
+    if stride == 1 and k % 32 == 0:
+        dx = ops.conv2d(dyd, ops.pack_conv_dgrad(wt.detach().to(DEV), pad))
+        close(dx.permute(0, 3, 1, 2), x.grad, msg="dgrad")
+        mask_src = rnd(4, n, h, w, c).to(DEV)
+        dxm = ops.conv2d(dyd, ops.pack_conv_dgrad(wt.detach().to(DEV), pad), relu=2, residual=mask_src)
+        close(dxm.permute(0, 3, 1, 2), x.grad * (mask_src.cpu().permute(0, 3, 1, 2) > 0), msg="dgrad+mask")
+
+
+def test_small_backward_kernels():
+    from seam_match_rcnn_amd import ops
+    # avg-pool + ReLU
+    pre = rnd(5, 6, 6, 6, 64).requires_grad_(True)
+    y = F.relu(pre)
+    pool = F.relu(y.mean((1, 2)))
+    dpool = rnd(6, 6, 64)
+    pool.backward(dpool)
+    close(ops.avgpool_relu_bwd(dpool.to(DEV), y.detach().to(DEV)), pre.grad, msg="avgpool_relu_bwd")
+    # BatchNorm1d, batch statistics
+    x = rnd(7, 13, 256).requires_grad_(True)
+    g, b = (rnd(8, 256) * 0.3 + 1).requires_grad_(True), rnd(9, 256).requires_grad_(True)
+    rm, rv = rnd(10, 256) * 0.1, rnd(11, 256).abs() + 0.5
+    rm_d, rv_d = rm.clone().to(DEV), rv.clone().to(DEV)
+    yb = F.batch_norm(x, rm, rv, g, b, True, 0.1, 1e-5)
+    dy = rnd(12, 13, 256)
+    yb.backward(dy)
+    yd, mean, inv = ops.bn1d_train_fwd(x.detach().to(DEV), g.detach().to(DEV), b.detach().to(DEV), rm_d, rv_d, 0.1, 1e-5)
+    close(yd, yb, msg="bn fwd"); close(rm_d, rm, msg="running_mean"); close(rv_d, rv, msg="running_var")
+    dx, dg, db = ops.bn1d_bwd(dy.to(DEV), x.detach().to(DEV), mean, inv, g.detach().to(DEV))
+    close(dx, x.grad, rtol=5e-4, msg="bn dx"); close(dg, g.grad, msg="bn dgamma"); close(db, b.grad, msg="bn dbeta")
+    with pytest.raises(ValueError):
+        ops.bn1d_train_fwd(x.detach()[:1].to(DEV), g.detach().to(DEV), b.detach().to(DEV), rm_d, rv_d, 0.1, 1e-5)
+    # pairwise classifier
+    a, bb = rnd(13, 9, 256).requires_grad_(True), rnd(14, 5, 256).requires_grad_(True)
+    w, bias = (rnd(15, 2, 256) * 0.1).requires_grad_(True), rnd(16, 2).requires_grad_(True)
+    x5 = OH.pair_logits(a, bb, w, bias)
+    gg = rnd(17, 9, 5, 2)
+    x5.backward(gg)
+    da, dbb, dw, dbias = ops.pair_logits_bwd(a.detach().to(DEV), bb.detach().to(DEV), w.detach().to(DEV), gg.to(DEV))
+    close(da, a.grad, msg="pair da"); close(dbb, bb.grad, msg="pair db"); close(dw, w.grad, msg="pair dw"); close(dbias, bias.grad, msg="pair dbias")
+    # weighted 2-class cross entropy
+    lg = rnd(18, 37, 2).requires_grad_(True)
+    tgt = torch.from_numpy((synth.uniform(synth.stream_id(19, "y"), (37,)) > 0.7).astype(np.int64))
+    wts = torch.tensor([1.0, 0.3])
+    loss = F.cross_entropy(lg, tgt, weight=wts)
+    loss.backward()
+    l, dl = ops.ce2_fwd_bwd(lg.detach().to(DEV), tgt.to(DEV), wts.to(DEV))
+    close(l, loss, msg="ce loss"); close(dl, lg.grad, msg="ce grad")
+
+
+@pytest.mark.parametrize("lens", [[3, 3, 3], [10, 1, 4, 7, 2], [1, 1], [30, 5]])
+def test_nlb_attnpool_backward(lens):
+    from seam_match_rcnn_amd import ops
+    from seam_match_rcnn_amd.models.match_head import pack_nlb_from_state
+    sd = to_torch(synth.temporal_aggregator_state(12))
+    names = ["newnlb.theta.weight", "newnlb.theta.bias", "newnlb.phi.weight", "newnlb.phi.bias", "newnlb.g.weight", "newnlb.g.bias",
+             "newnlb.concat_project.0.weight", "newnlb.W.weight", "newnlb.W.bias", "attention_scorer.weight", "attention_scorer.bias"]
+    p = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    t, s = max(lens), len(lens)
+    seq = rnd(20, t, s, 256)
+    for i, n in enumerate(lens):
+        seq[n:, i] = 0
+    seq.requires_grad_(True)
+    out, _ = OH.aggregate_sequences([seq[:n, i] for i, n in enumerate(lens)], p)
+    dout = rnd(21, s, 256)
+    out.backward(dout)
+    pk = pack_nlb_from_state({k: v.to(DEV) for k, v in sd.items()})
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    fwd, _ = ops.nlb_attnpool(seq.detach().to(DEV), s * 256, 256, lens_d, s, t, pk)
+    close(fwd, out, msg="fwd")
+    dseq, grads = ops.nlb_attnpool_bwd(seq.detach().to(DEV), s * 256, 256, lens_d, s, t, pk, dout.to(DEV))
+    close(dseq, seq.grad, msg="dseq")
+    for nm, gr in zip(names, grads):
+        want = p[nm].grad if p[nm].grad is not None else torch.zeros_like(p[nm])
+        close(gr, want, rtol=5e-4, atol_frac=5e-5, msg=nm, zero=ZERO_ALWAYS)
+
+
+def make_heads(n_frames=3):
+    from seam_match_rcnn_amd.models.match_head import MatchPredictor, TemporalAggregationNLB
+    mp, ta = MatchPredictor(), TemporalAggregationNLB()
+    mp.load_state_dict(to_torch(synth.match_predictor_state(11)))
+    ta.load_state_dict(to_torch(synth.temporal_aggregator_state(12)))
+    ta.n_frames = n_frames
+    return mp.to(DEV), ta.to(DEV)
+
+
+def engine_step(mp, ta, x, types, prod, img, weight_aggr=1.0):
+    """The grad-enabled pass of ref stuffs/engine.py:120-121,158-185 with the drop-in heads and losses."""
+    from seam_match_rcnn_amd.models.match_head import MatchLossWeak, NEWBalancedAggregationMatchLossWeak
+    mp.train(); ta.train()
+    match_loss, aggr_loss = MatchLossWeak(DEV), NEWBalancedAggregationMatchLossWeak(DEV, ta)
+    _, logits = mp(x, types)
+    l1 = match_loss(logits, types, prod, img)
+    l2 = aggr_loss(logits, types, prod, img, x)
+    (l1 + weight_aggr * l2).backward()
+    return logits, l1, l2
+
+
+def test_engine_step_matches_reference_fixture():
+    tg = dict(np.load(os.path.join(ROOT, "tests", "golden", "train_golden.npz")))
+    mp, ta = make_heads(3)
+    types = torch.from_numpy(tg["types"])                       # CPU IntTensor, as the engine builds it
+    x = torch.from_numpy(synth.roi_features(41, len(types))).to(DEV)
+    logits, l1, l2 = engine_step(mp, ta, x, types, tg["prod_ids"].tolist(), tg["img_ids"].tolist())
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), tg["logits"], rtol=2e-4, atol=2e-5 * float(np.abs(tg["logits"]).max()))
+    np.testing.assert_allclose(float(l1), float(tg["match_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(l2), float(tg["aggregation_loss"]), rtol=1e-4)
+    assert check_grads(tg, "mp.", {k: p.grad for k, p in mp.named_parameters()}, rtol=5e-4, atol_frac=1e-4, l2_keys=L2_KEYS) == 14
+    assert check_grads(tg, "ta.", {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in ta.named_parameters()},
+                       rtol=5e-4, atol_frac=1e-4, l2_keys=L2_KEYS) >= 24
+    for nm, m in (("mp", mp), ("ta", ta)):
+        bn = m.linear[1]
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), tg[f"{nm}.bn_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), tg[f"{nm}.bn_var"], rtol=1e-4, atol=1e-6)
+        assert int(bn.num_batches_tracked) == int(tg[f"{nm}.bn_n"])
+
+
+def test_df2_losses_match_reference_fixture():
+    from seam_match_rcnn_amd.models.match_head import MatchLossDF2, AggregationMatchLossDF2
+    tg = dict(np.load(os.path.join(ROOT, "tests", "golden", "train_golden.npz")))
+    mp, ta = make_heads(3)
+    mp.train(); ta.train()
+    types = torch.from_numpy(tg["types"])
+    x = torch.from_numpy(synth.roi_features(41, len(types))).to(DEV)
+    raw_gt = tg["df2_raw_gt"].tolist()
+    _, logits = mp(x, types)
+    d1 = MatchLossDF2(DEV)(logits, types, raw_gt)
+    d2 = AggregationMatchLossDF2(DEV, ta)(types, x, raw_gt)
+    (d1 + d2).backward()
+    np.testing.assert_allclose(float(d1), float(tg["df2_match_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(d2), float(tg["df2_aggregation_loss"]), rtol=1e-4)
+    assert check_grads(tg, "df2.mp.", {k: p.grad for k, p in mp.named_parameters()}, rtol=5e-4, atol_frac=1e-4, l2_keys=L2_KEYS) == 6
+    assert check_grads(tg, "df2.ta.", {k: p.grad for k, p in ta.named_parameters()}, rtol=5e-4, atol_frac=1e-4, l2_keys=L2_KEYS) == 7
+
+
+def test_engine_step_vs_oracle_ragged_and_optimizer_step():
+    """Another layout (n_frames = -1: sequences of 1..4 frames, incl. the length-1 NLB bypass) vs the oracle's autograd,
+    then an SGD step: the next forward must see the updated weights (no stale packed copies)."""
+    types, prod, img = [], [], []
+    i = 0
+    for p, frames in enumerate(([1], [2, 1, 1, 1], [1, 1], [2, 2, 1])):
+        types.append(1); prod.append(p); img.append(i); i += 1
+        for nb in frames:
+            types += [0] * nb; prod += [p] * nb; img += [i] * nb
+            i += 1
+    types_t = torch.IntTensor(types)
+    x = torch.from_numpy(synth.roi_features(43, len(types)))
+    mp, ta = make_heads(-1)
+    logits, l1, l2 = engine_step(mp, ta, x.to(DEV), types_t, prod, img, weight_aggr=0.5)
+    mps, tas = to_torch(synth.match_predictor_state(11)), to_torch(synth.temporal_aggregator_state(12))
+    ref = OL.train_step(x, types_t, prod, img, mps, tas, n_frames=-1, weight_aggr=0.5)
+    close(logits, ref["logits"], msg="logits")
+    np.testing.assert_allclose(float(l1), float(ref["match_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(l2), float(ref["aggregation_loss"]), rtol=1e-4)
+    for k, p in mp.named_parameters():
+        close(p.grad, ref["grads_mp"][k], rtol=1e-3, atol_frac=2e-4, msg="mp." + k, zero=ZERO_BN_TRAIN + ("mp.linear.1.bias",), l2=L2_KEYS)
+    for k, p in ta.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        close(g, ref["grads_ta"][k], rtol=1e-3, atol_frac=2e-4, msg="ta." + k, zero=ZERO_BN_TRAIN + ZERO_ALWAYS, l2=L2_KEYS)
+    close(mp.linear[1].running_var, mps["linear.1.running_var"], msg="bn buffers follow the oracle")
+    # optimizer step, then eval forward == oracle eval forward on the updated parameters
+    opt = torch.optim.SGD(list(mp.parameters()) + list(ta.parameters()), lr=0.05)
+    opt.step()
+    mp.eval(); ta.eval()
+    with torch.no_grad():
+        x3, x5 = mp(x.to(DEV), types_t)
+        out = ta(x.to(DEV), types_t, torch.tensor(img))
+    new_mp = {k: v.detach().cpu() for k, v in mp.state_dict().items()}
+    new_ta = {k: v.detach().cpu() for k, v in ta.state_dict().items()}
+    ox3, ox5 = OH.match_predictor_forward(x, types_t, new_mp)
+    close(x3, ox3, msg="x3 after step"); close(x5, ox5, msg="x5 after step")
+    oout = OH.temporal_aggregation_forward(x, types_t, torch.tensor(img), new_ta)
+    close(out[0], oout[0], msg="x3_1b after step"); close(out[2], oout[2], msg="aggregator x5 after step")
+    assert float((new_mp["conv_seq.0.weight"] - mps["conv_seq.0.weight"]).abs().max()) > 0
+
+
+def test_input_gradient_and_frozen_bn():
+    """eval-mode heads with autograd on (fine-tuning with frozen statistics) incl. the gradient w.r.t. the ROI features."""
+    mp, _ = make_heads()
+    mp.eval()
+    x = torch.from_numpy(synth.roi_features(44, 5))
+    types = torch.IntTensor([0, 1, 0, 1, 0])
+    xd = x.to(DEV).requires_grad_(True)
+    x3, x5 = mp(xd, types)
+    gsel, g3 = rnd(45, *x5.shape), rnd(46, *x3.shape)
+    ((x5 * gsel.to(DEV)).sum() + (x3 * g3.to(DEV)).sum()).backward()
+    p = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+         for k, v in to_torch(synth.match_predictor_state(11)).items()}
+    xc = x.clone().requires_grad_(True)
+    ox3, ox5 = OH.match_predictor_forward(xc, types, p)
+    ((ox5 * gsel).sum() + (ox3 * g3).sum()).backward()
+    close(x5, ox5, msg="x5")
+    close(xd.grad, xc.grad, rtol=1e-3, atol_frac=2e-4, msg="conv_seq: d roi_features", l2=L2_KEYS)
+    for k, prm in mp.named_parameters():
+        close(prm.grad, p[k].grad, rtol=1e-3, atol_frac=2e-4, msg=k, l2=L2_KEYS)
