@@ -252,11 +252,12 @@ int seam_mask_select_f16(const void* logits, const int64_t* labels, float* prob,
  * seam_conv_wgrad_f32: dw [K,C,R,S] (OIHW) = sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,ho*stride+r-pad,wo*stride+s-pad,c]
  *   for x NHWC [N,H,W,C], dy NHWC [N,Ho,Wo,K]; C,K multiples of 4.  fp32-MFMA GEMM split over the pixel
  *   axis; ws: >= seam_conv_wgrad_workspace_floats(M = N*Ho*Wo, C, K, R, S) floats.  (Linear: R=S=1, H=W=1.)
- * seam_colsum_f32: out[k] = sum_m x[m,k]  (bias gradients). */
+ * seam_colsum_f32: out[k] = sum_m x[m,k]  (bias gradients); ws: >= seam_colsum_workspace_floats(M,K) floats. */
 int64_t seam_conv_wgrad_workspace_floats(int M, int C, int K, int R, int S);
 int seam_conv_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K,
                         int R, int S, int stride, int pad, float* ws, seam_stream_t stream);
-int seam_colsum_f32(const float* x, float* out, int M, int K, seam_stream_t stream);
+int64_t seam_colsum_workspace_floats(int M, int K);
+int seam_colsum_f32(const float* x, float* out, int M, int K, float* ws, seam_stream_t stream);
 
 /* Backward of conv_seq's last ReLU -> AvgPool2d(6,6) -> ReLU (models/match_head.py:56-60):
  * dy[n,hw,c] = y[n,hw,c] > 0 ? dpool[n,c] / HW : 0   (y = the ReLU'd conv output, NHWC [N,HW,C]). */

@@ -67,7 +67,8 @@ SIGNATURES = {
     "seam_mask_select_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_conv_wgrad_workspace_floats": (_i64, [_i, _i, _i, _i, _i]),
     "seam_conv_wgrad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
-    "seam_colsum_f32": (_i, [_p, _p, _i, _i, _p]),
+    "seam_colsum_workspace_floats": (_i64, [_i, _i]),
+    "seam_colsum_f32": (_i, [_p, _p, _i, _i, _p, _p]),
     "seam_avgpool_relu_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "seam_bn1d_train_fwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _p]),
     "seam_bn1d_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

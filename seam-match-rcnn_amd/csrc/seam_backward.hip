@@ -153,16 +153,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
-// out[k] = sum_m x[m][k]   (bias gradients).  256 threads = 4 row groups x 64 columns.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int K) {
+// out[k] = sum_m x[m][k]   (bias gradients), two fixed-order stages: blockIdx.y sums a contiguous slab of rows into
+// part[y][k] (256 threads = 4 row groups x 64 columns), then colsum_final adds the slabs.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ partial, int M, int K,
+                                                     int rows_per) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
     float acc = 0.f;
     if (c < K)
-        for (int m = g; m < M; m += 4) acc += x[(size_t)m * K + c];
+        for (int m = m0 + g; m < m1; m += 4) acc += x[(size_t)m * K + c];
     part[g][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (g == 0 && c < K) out[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (g == 0 && c < K)
+        partial[(size_t)blockIdx.y * K + c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int slabs, int K) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    float acc = 0.f;
+    for (int i = 0; i < slabs; ++i) acc += partial[(size_t)i * K + c];
+    out[c] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ pool / BN
@@ -614,9 +626,19 @@ int seam_conv_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H
     return (int)hipGetLastError();
 }
 
-int seam_colsum_f32(const float* x, float* out, int M, int K, void* stream) {
+static int colsum_slabs(int M) {
+    int slabs = (M + 127) / 128;
+    return slabs > 128 ? 128 : (slabs < 1 ? 1 : slabs);
+}
+
+int64_t seam_colsum_workspace_floats(int M, int K) { return (int64_t)colsum_slabs(M) * K; }
+
+int seam_colsum_f32(const float* x, float* out, int M, int K, float* ws, void* stream) {
     if (K <= 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, out, M, K);
+    const int slabs = colsum_slabs(M);
+    const int rows_per = (M + slabs - 1) / slabs;
+    hipLaunchKernelGGL(colsum_kernel, dim3((K + 63) / 64, slabs), dim3(256), 0, (hipStream_t)stream, x, ws, M, K, rows_per);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, out, slabs, K);
     return (int)hipGetLastError();
 }
 

@@ -152,8 +152,11 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     """[..., K] -> [K] sum over all leading dims (bias gradients)."""
     x = _req(x)
     k = x.shape[-1]
+    m = x.numel() // k
+    lib = _native.lib()
     out = torch.empty((k,), dtype=F32, device=x.device)
-    _native.check(_native.lib().seam_colsum_f32(_ptr(x), _ptr(out), x.numel() // k, k, _stream()), "seam_colsum_f32")
+    ws = torch.empty((int(lib.seam_colsum_workspace_floats(m, k)),), dtype=F32, device=x.device)
+    _native.check(lib.seam_colsum_f32(_ptr(x), _ptr(out), m, k, _ptr(ws), _stream()), "seam_colsum_f32")
     return out
 
 
