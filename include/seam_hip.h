@@ -297,6 +297,21 @@ int seam_nlb_attnpool_bwd_f32(const float* seq, int64_t t_stride, int64_t s_stri
                               const float* b_att, const float* dout, float* dseq, float* const* grads,
                               float* ws, int use_nlb, seam_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Input pipeline on the device: what MovingFashionDataset.__getitem__ does to a decoded
+ * frame (datasets/MFDataset.py:79-93), on uint8 [H,W,3] device images.
+ *
+ * seam_frame_noise_u8: rgb = uint8(clip((bgr[...,::-1] / 255.0 + n * sigma) * 255.0, 0, 255)), float64 like NumPy;
+ *   n = noise[H,W,3] float64 standard-normal draws, or (noise NULL) counter-based draws keyed by `seed`;
+ *   sigma 0 with noise NULL = the noise=False branch (channel flip only).
+ * seam_resize_bicubic_u8: PIL Image.resize((OW,OH)) -- BICUBIC, antialiased, 8-bit fixed point, horizontal then
+ *   vertical pass -- bit-identical to Pillow (MFDataset.py:92: half resolution); ws: seam_resize_workspace_bytes. */
+int seam_frame_noise_u8(const uint8_t* bgr, const double* noise, uint8_t* rgb, int H, int W, double sigma,
+                        uint64_t seed, seam_stream_t stream);
+int64_t seam_resize_workspace_bytes(int H, int W, int OH, int OW);
+int seam_resize_bicubic_u8(const uint8_t* in, uint8_t* out, int H, int W, int OH, int OW, void* ws,
+                           seam_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

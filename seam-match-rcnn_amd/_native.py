@@ -72,6 +72,9 @@ SIGNATURES = {
     "seam_avgpool_relu_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "seam_bn1d_train_fwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _p]),
     "seam_bn1d_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "seam_frame_noise_u8": (_i, [_p, _p, _p, _i, _i, C.c_double, C.c_uint64, _p]),
+    "seam_resize_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "seam_resize_bicubic_u8": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "seam_ce2_fwd_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
     "seam_pair_logits_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "seam_nlb_bwd_workspace_floats": (_i64, [_i, _i]),

@@ -574,3 +574,32 @@ def mask_select(logits: torch.Tensor, labels: torch.Tensor, ncls: int) -> torch.
     fn = getattr(_native.lib(), "seam_mask_select_" + _sfx(logits.dtype))
     _native.check(fn(_ptr(logits), _ptr(labels), _ptr(out), k, ncls, _stream()), "seam_mask_select")
     return out
+
+
+# ------------------------------------------------------------------------------ input pipeline (row f4)
+def frame_noise(bgr: torch.Tensor, sigma: float, noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
+    """uint8 [H,W,3] BGR -> uint8 [H,W,3] RGB with additive noise (float64 maths, ref datasets/MFDataset.py:81-88).
+    noise: float64 [H,W,3] standard-normal draws, or None for on-device counter-based draws keyed by ``seed``;
+    sigma == 0 and noise None: channel flip only (the dataset's noise=False branch)."""
+    bgr = _req(bgr, torch.uint8, "bgr")
+    if bgr.dim() != 3 or bgr.shape[2] != 3:
+        raise ValueError("frame must be uint8 [H,W,3]")
+    if noise is not None:
+        noise = _req(noise, torch.float64, "noise")
+        if noise.shape != bgr.shape:
+            raise ValueError("noise must have the frame's shape")
+    out = torch.empty_like(bgr)
+    _native.check(_native.lib().seam_frame_noise_u8(_ptr(bgr), _ptr(noise), _ptr(out), bgr.shape[0], bgr.shape[1], float(sigma),
+                                                    int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), "seam_frame_noise_u8")
+    return out
+
+
+def resize_bicubic_u8(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """``PIL.Image.resize((out_w, out_h))`` (BICUBIC, antialiased, 8-bit fixed point) on a uint8 [H,W,3] device image."""
+    lib = _native.lib()
+    img = _req(img, torch.uint8, "img")
+    h, w = img.shape[0], img.shape[1]
+    out = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=img.device)
+    ws = torch.empty((int(lib.seam_resize_workspace_bytes(h, w, out_h, out_w)),), dtype=torch.uint8, device=img.device)
+    _native.check(lib.seam_resize_bicubic_u8(_ptr(img), _ptr(out), h, w, out_h, out_w, _ptr(ws), _stream()), "seam_resize_bicubic_u8")
+    return out
