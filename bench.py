@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2",
                     help="c2 (default, the BASELINE metric's config): 10 x 800x800 frames, 32 ROI/frame, fp32; "
                          "c5: configs[4] per-GPU shape -- 30 x 1080x1920 frames, 64 ROI/frame (use with --dtype f16)")
-    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "f16", "bf16x3"), default="f32",
                     help="f32 (default, the headline: exact fp32 MFMA) | f16 (config-5 style fp16 MFMA, fp32 accumulate; "
                          "extractor + trunks in fp16, descriptors / NLB / match logits fp32)")
     return ap.parse_args()
@@ -103,6 +103,8 @@ def main():
     model, sd = build_model(dev)
     if args.dtype == "f16":
         model.set_compute_dtype(torch.float16)
+    elif args.dtype == "bf16x3":      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product), fp32 accumulate
+        model.set_compute_dtype(ops.BX3)
     log("weights on device; generating frames")
     ta = model.roi_heads.temporal_aggregator
     frames = torch.from_numpy(synth.frames(rank, T, H, W)).to(dev)           # clip of this rank, resident
@@ -186,6 +188,7 @@ def main():
         peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else F16_MFMA_PEAK_TFLOPS
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    **({"mfma_passes_per_product": 3, "issued_frac": round(3 * achieved / peak, 4)} if args.dtype == "bf16x3" else {}),
                     "traffic": pmc_traffic(dom), "algorithmic_bytes_per_launch": round(alg_bytes / n),
                     "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),

@@ -245,6 +245,18 @@ int seam_mask_select_f16(const void* logits, const int64_t* labels, float* prob,
                          seam_stream_t stream);   /* fp16 logits in, fp32 probabilities out */
 
 /* ---------------------------------------------------------------------------------------------------
+ * Split-bf16 ("bx3") convolution: the same contraction as seam_conv2d_f32 on fp32 activations, computed as
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with v_mfma_f32_32x32x16_bf16 and fp32 accumulation (relative error ~1e-5 per
+ * product, fp32 exponent range; well inside the 1e-3 contract of BASELINE.json).  Same call sites as
+ * seam_conv2d_f32 (opt-in: model.set_compute_dtype("bf16x3")).  Weights: seam_pack_conv_weight_bx3 (same size as
+ * the fp32 pack; tmp = rows_padded*kred floats of scratch). */
+int seam_pack_conv_weight_bx3(const float* w, void* w_packed, float* tmp, int K, int Cin, int R, int S,
+                              int Cstore, int mode, seam_stream_t stream);
+int seam_conv2d_bx3(const float* x, const void* w_packed, const float* scale, const float* shift,
+                    const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S,
+                    int stride, int pad, int relu, seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Gradient kernels of the match heads: the grad-enabled pass of the training loop,
  * stuffs/engine.py:120-121,158-168,183-185 -> MatchPredictor / TemporalAggregationNLB in .train()
  * (models/match_head.py:66-76,90-169,339).  fp32, fixed-order reductions (bit-reproducible).

@@ -31,6 +31,8 @@ SIGNATURES = {
     "seam_conv_tile": (_i, [_i, _i]),
     "seam_pack_conv_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_pack_conv_weight_bx3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv2d_bx3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv_kred_f16": (_i, [_i, _i, _i]),
     "seam_pack_conv_weight_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

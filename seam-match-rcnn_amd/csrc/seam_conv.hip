@@ -337,6 +337,295 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
     }
 }
 
+// =====================================================================================================================
+// Split-bf16 variant ("bx3"): fp32 activations in HBM, 3 bf16 MFMAs per product, fp32 accumulate.
+//   a = a_hi + a_lo (both bf16, a_hi = rn(a), a_lo = rn(a - a_hi)):  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, relative
+//   error <= ~3 * 2^-18 per product (the dropped lo*lo term and the two roundings of the lo parts) -- 1e-5, two orders
+//   inside the 1e-3 contract, with the fp32 exponent range (no overflow / underflow hazards of an fp16 split).
+//   v_mfma_f32_32x32x16_bf16 issues 16x the FLOPs of the fp32 MFMA per cycle, so three of them per k-step are still
+//   5.3x faster than the exact-fp32 path on the matrix pipe.
+// Operands: the A gather is the fp32 kernel's (same buffer loads, same chunk walk: 32 k-values = 128 B per row);
+//   the split of A happens ONCE per block at the LDS store (10 VALU per 16 B).  Weights are split at pack time
+//   (seam_pack_conv_weight_bx3): a packed row of a chunk is [32 hi | 32 lo] bf16 = the same 128 B as an fp32 row.
+// LDS: hi and lo planes, rows of exactly 64 B (32 bf16), XOR-swizzled 16-B slots (slot ^ ((row >> 2) & 3)): the
+//   ds_read_b128 lane groups {0-3,12-15,20-27}/{4-11,16-19,28-31} land on 4 distinct slots => conflict-free without
+//   padding; 64 KiB per block at 128x128 (two blocks per CU).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_bf16(const f32x4 v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2 x = {v[2 * p], v[2 * p + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        const f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        hi[p] = hb;
+        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, bf16x2));
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bx3(const ConvArgs p) {
+    constexpr int ES = 4, EPV = 4, BKE = 32;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int Q = 3 * MT * NT;               // MFMAs per k-step (16 k-values)
+    constexpr int PA = BM * 64 + 64;             // bytes of one A plane (+64: the lo plane starts on the other bank half)
+    constexpr int PB = BN * 64 + 64;
+
+    __shared__ __attribute__((aligned(16))) char As[2][2 * PA];     // [buffer][hi plane | lo plane]
+    __shared__ __attribute__((aligned(16))) char Bs[2][2 * PB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm0 = (wid >> 1) * WM;
+    const int wn0 = (wid & 1) * WN;
+
+    const int nblk = gridDim.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int q8 = nblk >> 3, rem = nblk & 7;
+    const int tile = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (b >> 3);
+    const int tm = tile / p.tiles_n;
+    const int tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    const int nk = p.kred / BKE;
+    const int lcol = tid & 7;
+    const int lrow = tid >> 3;
+    const int HoWo = p.Ho * p.Wo;
+    const int n_first = m0 / HoWo;
+    const size_t img_elems = (size_t)p.H * p.W * p.C;
+    const size_t rem_bytes = ((size_t)(p.N - n_first) * img_elems) * ES;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.x + (size_t)n_first * img_elems * ES), 0,
+        (int)(rem_bytes > kOob ? kOob : (unsigned)rem_bytes), 0x00020000);
+    const int slab_stride = p.slab_bn * CHUNK_BYTES;
+    const int n_in_slab = n0 % p.slab_bn;
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.w + (size_t)(n0 - n_in_slab) * p.kred * ES + (size_t)n_in_slab * CHUNK_BYTES), 0,
+        (int)((unsigned)nk * (unsigned)slab_stride), 0x00020000);
+
+    int arow[AI], ahi[AI], awi[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int n = m / HoWo;
+            const int rm = m - n * HoWo;
+            const int ho = rm / p.Wo;
+            const int wo = rm - ho * p.Wo;
+            ahi[i] = ho * p.stride - p.pad;
+            awi[i] = wo * p.stride - p.pad;
+            arow[i] = ((((n - n_first) * p.H + ahi[i]) * p.W + awi[i]) * p.C) * ES;
+        } else {
+            ahi[i] = -(1 << 28);
+            awi[i] = 0;
+            arow[i] = 0;
+        }
+    }
+    int brow[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) brow[i] = (lrow + 32 * i) * CHUNK_BYTES + lcol * 16;
+
+    int kc, kr, ks, tapoff;
+    {
+        const int kk = lcol * EPV;
+        const int pos = kk / p.C;
+        kc = kk - pos * p.C;
+        kr = pos / p.S;
+        ks = pos - kr * p.S;
+        tapoff = ((kr * p.W + ks) * p.C + kc) * ES;
+    }
+    int uq = 0;
+
+    constexpr int D = 2;
+    f32x4 areg[D][AI], breg[D][BI];
+    auto load_a = [&](f32x4 (&ar)[AI], int i) {
+        const bool ok = (unsigned)(ahi[i] + kr) < (unsigned)p.H && (unsigned)(awi[i] + ks) < (unsigned)p.W && kr < p.R;
+        const unsigned off = ok ? (unsigned)(arow[i] + tapoff) : kOob;
+        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
+    };
+    auto load_b = [&](f32x4 (&br)[BI], int i) {
+        const int so = uq < nk ? uq * slab_stride : (int)kOob;
+        br[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, brow[i], so, 0));
+    };
+    auto advance_k = [&]() {
+        ++uq;
+        if (p.C >= BKE) {
+            if (++ks == p.S) {
+                ks = 0;
+                kc += BKE;
+                if (kc >= p.C) { kc -= p.C; ++kr; }
+            }
+        } else {
+            kc += BKE;
+            while (kc >= p.C) {
+                kc -= p.C;
+                if (++ks == p.S) { ks = 0; ++kr; }
+            }
+        }
+        tapoff = ((kr * p.W + ks) * p.C + kc) * ES;
+    };
+    auto load_chunk = [&](f32x4 (&ar)[AI], f32x4 (&br)[BI]) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) load_a(ar, i);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) load_b(br, i);
+        advance_k();
+    };
+    // LDS addresses of this thread's stores.  A: 4 floats -> 8 B of hi + 8 B of lo at bf16 index 4*lcol of the row;
+    // B: 16 B of the packed row: lcol < 4 -> hi plane slot lcol, else lo plane slot lcol-4.
+    auto store_row = [&](const f32x4 (&ar)[AI], const f32x4 (&br)[BI], int buf, int r) {
+        if (r < AI) {
+            const int row = lrow + 32 * r;
+            const int off = row * 64 + ((((lcol >> 1) ^ (row >> 2)) & 3) << 4) + (lcol & 1) * 8;
+            u32x2 hi, lo;
+            split_bf16(ar[r], hi, lo);
+            *reinterpret_cast<u32x2*>(&As[buf][off]) = hi;
+            *reinterpret_cast<u32x2*>(&As[buf][PA + off]) = lo;
+        } else {
+            const int row = lrow + 32 * (r - AI);
+            const int off = (lcol >> 2) * PB + row * 64 + (((lcol ^ (row >> 2)) & 3) << 4);
+            *reinterpret_cast<f32x4*>(&Bs[buf][off]) = br[r - AI];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: lane reads 16 B (8 bf16 of k) of row (l & 31) at slot 2*step + (l >> 5), swizzled
+    const int arow0 = wm0 + (lane & 31), brow0 = wn0 + (lane & 31);
+    struct Frag { f32x4 ah[MT], al[MT], bh[NT], bl[NT]; };
+    Frag f0, f1;
+    auto read_frags = [&](Frag& f, int buf, int step) {
+        const int slot = 2 * step + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = arow0 + i * 32;
+            const int off = row * 64 + (((slot ^ (row >> 2)) & 3) << 4);
+            f.ah[i] = *reinterpret_cast<const f32x4*>(&As[buf][off]);
+            f.al[i] = *reinterpret_cast<const f32x4*>(&As[buf][PA + off]);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int row = brow0 + j * 32;
+            const int off = row * 64 + (((slot ^ (row >> 2)) & 3) << 4);
+            f.bh[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][off]);
+            f.bl[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][PB + off]);
+        }
+    };
+    auto mf = [&](const Frag& f, int idx) {       // idx in [0, Q): term-major so the small terms of a tile go in first
+        const int term = idx / (MT * NT), i = (idx / NT) % MT, j = idx % NT;
+        const f32x4 a = term == 1 ? f.al[i] : f.ah[i];
+        const f32x4 bq = term == 0 ? f.bl[j] : f.bh[j];          // 0: hi*lo, 1: lo*hi, 2: hi*hi
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq),
+                                                            acc[i][j], 0, 0, 0);
+    };
+
+    auto chunk = [&](int buf, f32x4 (&lda)[AI], f32x4 (&ldb)[BI], const f32x4 (&sta)[AI], const f32x4 (&stb)[BI]) {
+        // k-step 0 (+ the gathers and weight rows of chunk t+D)
+        read_frags(f1, buf, 1);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            mf(f0, q);
+#pragma unroll
+            for (int i = 0; i < AI + BI; ++i)
+                if ((i * Q) / (AI + BI) == q) {
+                    if (i < AI) load_a(lda, i);
+                    else load_b(ldb, i - AI);
+                }
+            if (q == Q - 1) advance_k();
+        }
+        // k-step 1: chunk t+1 goes to the other LDS buffer behind the first two thirds of the MFMAs, then the barrier
+        // and the first fragments of the next chunk; the last third covers their latency
+        constexpr int QS = (2 * Q) / 3;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            mf(f1, q);
+#pragma unroll
+            for (int r = 0; r < AI + BI; ++r)
+                if ((r * QS) / (AI + BI) == q) store_row(sta, stb, buf ^ 1, r);
+            if (q == QS - 1) {
+                __syncthreads();
+                read_frags(f0, buf ^ 1, 0);
+            }
+        }
+    };
+
+    load_chunk(areg[0], breg[0]);
+#pragma unroll
+    for (int r = 0; r < AI + BI; ++r) store_row(areg[0], breg[0], 0, r);
+    load_chunk(areg[1], breg[1]);
+    __syncthreads();
+    read_frags(f0, 0, 0);
+
+    for (int t = 0; t < nk; t += 2) {
+        chunk(0, areg[0], breg[0], areg[1], breg[1]);
+        if (t + 1 < nk) chunk(1, areg[1], breg[1], areg[0], breg[0]);
+    }
+
+    // ---- epilogue (the fp32 kernel's) ---------------------------------------------------------
+    const size_t tile_off = (size_t)m0 * p.K;
+    const unsigned rows_here = (unsigned)min(BM, p.M - m0);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)p.y + tile_off * 4), 0, (int)(rows_here * (unsigned)p.K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(p.res ? p.res : p.y) + tile_off * 4), 0, (int)(rows_here * (unsigned)p.K * 4), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const bool nok = n < p.K;
+        const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
+        const float sh = (p.shift && nok) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            unsigned eo[16];
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                eo[r] = (unsigned)(row * p.K + n);
+            }
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, nok ? eo[r] * 4u : kOob, 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] * sc + sh;
+                if (p.res) v = p.relu == 2 ? (rv[r] > 0.f ? v : 0.f) : v + rv[r];
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, nok ? eo[r] * 4u : kOob, 0, 0);
+            }
+        }
+    }
+}
+
+// Re-layout of fp32-packed weights [..][row][32 floats] -> [..][row][32 hi bf16 | 32 lo bf16] (same 128 B per row-chunk)
+__global__ void split_weight_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = in[i];
+        const __bf16 h = (__bf16)x;
+        const __bf16 l = (__bf16)(x - (float)h);
+        const size_t rowchunk = i >> 5;
+        const int col = (int)(i & 31);
+        out[rowchunk * 64 + col] = __builtin_bit_cast(unsigned short, h);
+        out[rowchunk * 64 + 32 + col] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
 // OIHW fp32 [K,Cin,R,S] -> tile-contiguous packed weights of type T: [rows/BN][kred/BKE][BN][BKE].
 // Chunk q of the reduction covers, for Cstore >= BKE: tap row r = q / (S*Cstore/BKE), channel chunk
 // cc = (q / S) % (Cstore/BKE), tap column s = q % S, channels cc*BKE ..; for Cstore < BKE (stem):
@@ -454,6 +743,34 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     return (int)hipGetLastError();
 }
 
+int conv2d_bx3(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
+               int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, void* stream) {
+    if ((C % 4) || (C >= 32 && C % 32) || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+    ConvArgs a;
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.C = C;
+    a.Ho = (H + 2 * pad - R) / stride + 1;
+    a.Wo = (W + 2 * pad - S) / stride + 1;
+    a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+    a.kred = kred_of<float>(C, R, S);
+    a.M = N * a.Ho * a.Wo;
+    a.relu = relu;
+    a.y_f32 = 1;
+    if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
+    const int rows = ((K + 63) / 64) * 64;
+    a.slab_bn = rows % 128 == 0 ? 128 : 64;
+    int best_bm, best_bn;
+    choose_tile(a.M, K, best_bm, best_bn);
+    a.tiles_m = (a.M + best_bm - 1) / best_bm;
+    a.tiles_n = rows / best_bn;
+    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm_bx3<128, 128>), grid, block, 0, (hipStream_t)stream, a);
+    else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm_bx3<128, 64>), grid, block, 0, (hipStream_t)stream, a);
+    else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm_bx3<64, 128>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_igemm_bx3<64, 64>), grid, block, 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -487,6 +804,24 @@ int seam_conv2d_f16(const void* x, const void* w_packed, const float* scale, con
                     void* y, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu,
                     int y_f32, void* stream) {
     return conv2d<_Float16>(x, w_packed, scale, shift, residual, y, N, H, W, C, K, R, S, stride, pad, relu, y_f32, stream);
+}
+
+/* Split-bf16 path: weights = seam_pack_conv_weight_f32's layout with every 128-byte row-chunk re-written as
+ * [32 hi bf16 | 32 lo bf16]; `tmp` = rows_padded*kred floats of scratch (the fp32 pack). */
+int seam_pack_conv_weight_bx3(const float* w, void* w_packed, float* tmp, int K, int Cin, int R, int S, int Cstore, int mode,
+                              void* stream) {
+    const int rc = pack_weight<float>(w, tmp, K, Cin, R, S, Cstore, mode, stream);
+    if (rc) return rc;
+    const size_t total = (size_t)(((K + 63) / 64) * 64) * kred_of<float>(Cstore, R, S);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tmp, (unsigned short*)w_packed, total);
+    return (int)hipGetLastError();
+}
+
+int seam_conv2d_bx3(const float* x, const void* w_packed, const float* scale, const float* shift, const float* residual,
+                    float* y, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, void* stream) {
+    return conv2d_bx3(x, w_packed, scale, shift, residual, y, N, H, W, C, K, R, S, stride, pad, relu, stream);
 }
 
 }  // extern "C"

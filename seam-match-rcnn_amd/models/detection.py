@@ -35,15 +35,21 @@ def _key(params, dtype=None) -> tuple:
     return tuple((p.data_ptr(), p._version) for p in params) + (dtype,)
 
 
-def cdt(module) -> torch.dtype:
-    """Compute precision of a module: torch.float32 (exact, default) or torch.float16 (the fp16-MFMA /
-    fp32-accumulate path of BASELINE config 5).  Set for a whole model with ``set_compute_dtype``."""
+def cdt(module):
+    """Operand precision of a module's contractions: torch.float32 (exact fp32 MFMA, default), torch.float16 (the
+    fp16-MFMA / fp32-accumulate path of BASELINE config 5) or ops.BX3 = "bf16x3" (fp32 activations, split-bf16 operands,
+    3 bf16 MFMAs per product, fp32 accumulate: ~1e-5 relative).  Set for a whole model with ``set_compute_dtype``."""
     return getattr(module, "compute_dtype", torch.float32)
 
 
-def set_compute_dtype(model: nn.Module, dtype: torch.dtype) -> nn.Module:
-    if dtype not in (torch.float32, torch.float16):
-        raise ValueError("compute dtype must be torch.float32 or torch.float16")
+def adt(module) -> torch.dtype:
+    """Storage type of a module's activations: fp16 only on the fp16 path."""
+    return torch.float16 if cdt(module) == torch.float16 else torch.float32
+
+
+def set_compute_dtype(model: nn.Module, dtype) -> nn.Module:
+    if dtype not in (torch.float32, torch.float16, ops.BX3):
+        raise ValueError('compute dtype must be torch.float32, torch.float16 or "bf16x3"')
     for m in model.modules():
         m.compute_dtype = dtype
     return model
@@ -72,7 +78,7 @@ class GeneralizedRCNNTransform(nn.Module):
         d = self.size_divisible
         hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
         wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
-        return ops.preprocess(images, sizes, hp, wp, cdt(self)), sizes, orig
+        return ops.preprocess(images, sizes, hp, wp, adt(self)), sizes, orig
 
     @staticmethod
     def rescale_boxes(boxes: torch.Tensor, from_hw, to_hw) -> torch.Tensor:
@@ -139,7 +145,7 @@ class ResNet50Body(nn.Module):
         if self._pk is None or key != self._pk_key:
             with torch.no_grad():
                 pk = {"stem": ops.pack_conv(self.conv1.weight, None, self.bn1.tensors(), stride=2, pad=3,
-                                            cstore=4 if dt == torch.float32 else 8, bn_eps=self.bn1.eps, dtype=dt)}
+                                            cstore=8 if dt == torch.float16 else 4, bn_eps=self.bn1.eps, dtype=dt)}
                 for li in range(1, 5):
                     for bi, b in enumerate(getattr(self, f"layer{li}")):
                         e = {"c1": ops.pack_conv(b.conv1.weight, None, b.bn1.tensors(), bn_eps=b.bn1.eps, dtype=dt),

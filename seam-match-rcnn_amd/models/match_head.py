@@ -142,7 +142,8 @@ class MatchPredictor(nn.Module):
         """x NCHW [K,256,14,14] (the reference's layout) -> x3 [K,256]."""
         if _wants_tape(self, x):
             return self.trunk_taped(x)
-        return self.trunk_nhwc(ops.nchw_to_nhwc(x.detach().to(torch.float32), getattr(self, "compute_dtype", torch.float32)))
+        dt = getattr(self, "compute_dtype", torch.float32)
+        return self.trunk_nhwc(ops.nchw_to_nhwc(x.detach().to(torch.float32), torch.float16 if dt == torch.float16 else torch.float32))
 
     def trunk_taped(self, x: torch.Tensor) -> torch.Tensor:
         """The trunk as ONE autograd node (fp32): forward kernels + BatchNorm1d batch statistics when the BN layer

@@ -56,7 +56,10 @@ class PackedConv:
     stride: int = 1
     pad: int = 0
     Cin: int = 0                    # real (unpadded) input channels: algorithmic FLOP accounting
-    dtype: torch.dtype = F32        # operand precision of the packed weights (fp32 | fp16)
+    dtype: object = F32             # operand precision of the packed weights: torch.float32 | torch.float16 | BX3
+
+
+BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
 
 
 # When set to a list, every conv launch is bracketed by HIP events on the launch stream and
@@ -85,7 +88,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         weight = weight.contiguous()
         K, cin, R, S = weight.shape
         mode = 0
-    epv = 4 if dtype == F32 else 8
+    epv = 8 if dtype == F16 else 4
     cs = cstore if cstore is not None else ((cin + epv - 1) // epv) * epv
     rows = lib.seam_conv_rows_padded(K)
     if dtype == F32:
@@ -93,6 +96,12 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
         _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
                       "seam_pack_conv_weight_f32")
+    elif dtype == BX3:
+        kred = lib.seam_conv_kred(cs, R, S)
+        wp = torch.empty((rows, kred), dtype=F32, device=weight.device)      # opaque: [32 hi | 32 lo] bf16 per 128-byte row-chunk
+        tmp = torch.empty((rows, kred), dtype=F32, device=weight.device)
+        _native.check(lib.seam_pack_conv_weight_bx3(_ptr(weight), _ptr(wp), _ptr(tmp), K, cin, R, S, cs, mode, _stream()),
+                      "seam_pack_conv_weight_bx3")
     else:
         kred = lib.seam_conv_kred_f16(cs, R, S)
         wp = torch.empty((rows, kred), dtype=F16, device=weight.device)
@@ -246,16 +255,16 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     The precision (fp32 exact / fp16 MFMA with fp32 accumulate) is that of the packed weights;
     ``out_f32`` makes the fp16 kernel write fp32 (hand-off to the fp32 descriptor heads)."""
     x = _req(x, None, "x")             # device check first: CPU tensors fail loudly
-    x = _req(x, pc.dtype, "x")
+    x = _req(x, F16 if pc.dtype == F16 else F32, "x")
     n, h, w, c = x.shape
     if c != pc.Cstore:
         raise ValueError(f"conv2d: input has {c} channels, weights packed for {pc.Cstore}")
     ho = (h + 2 * pc.pad - pc.R) // pc.stride + 1
     wo = (w + 2 * pc.pad - pc.S) // pc.stride + 1
-    ydt = F32 if (pc.dtype == F32 or out_f32) else F16
+    ydt = F32 if (pc.dtype != F16 or out_f32) else F16
     y = out if out is not None else torch.empty((n, ho, wo, pc.K), dtype=ydt, device=x.device)
     if residual is not None:
-        residual = _req(residual, pc.dtype, "residual")
+        residual = _req(residual, F16 if pc.dtype == F16 else F32, "residual")
         if residual.shape != y.shape:
             raise ValueError("conv2d: residual shape mismatch")
     trace = CONV_TRACE
@@ -267,15 +276,21 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         _native.check(lib.seam_conv2d_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                           n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, int(relu), _stream()),
                       "seam_conv2d_f32")
+    elif pc.dtype == BX3:
+        _native.check(lib.seam_conv2d_bx3(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
+                                          n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, int(relu), _stream()),
+                      "seam_conv2d_bx3")
     else:
         _native.check(lib.seam_conv2d_f16(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                           n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, 1 if relu else 0,
                                           1 if out_f32 else 0, _stream()), "seam_conv2d_f16")
     if trace is not None:
         e1.record()
-        tag = "float" if pc.dtype == F32 else "_Float16"
         tile = lib.seam_conv_tile(n * ho * wo, pc.K)
-        variant = f"conv_igemm<{tag},{tile // 1000},{tile % 1000}>"
+        if pc.dtype == BX3:
+            variant = f"conv_igemm_bx3<{tile // 1000},{tile % 1000}>"
+        else:
+            variant = f"conv_igemm<{'float' if pc.dtype == F32 else '_Float16'},{tile // 1000},{tile % 1000}>"
         es = x.element_size()
         trace.append((variant, 2.0 * n * ho * wo * pc.K * pc.R * pc.S * (pc.Cin or pc.Cstore), e0, e1,
                       (n, h, w, c, pc.K, pc.R, pc.stride),

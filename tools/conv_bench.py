@@ -11,7 +11,9 @@ DEFAULT = ["10,200,200,256,256,3,1,1,0", "320,14,14,256,256,3,1,1,0", "10,200,20
            "10,50,50,256,1024,1,1,0,1", "320,8,8,256,1024,3,1,0,0", "10,200,200,64,64,3,1,1,0",
            "10,800,800,4,64,7,2,3,0", "10,25,25,256,256,3,1,1,0", "320,1,1,1024,256,1,1,0,0"]
 f16 = "--f16" in sys.argv
+bx3 = "--bx3" in sys.argv
 dt = torch.float16 if f16 else torch.float32
+pdt = ops.BX3 if bx3 else dt
 shapes = [a for a in sys.argv[1:] if not a.startswith("--")] or DEFAULT
 dev = torch.device("cuda:0")
 print(f"{'N,H,W,C,K,R,s,p,res':>30} {'us':>9} {'TF/s':>7} {'GB/s(alg)':>10}")
@@ -22,7 +24,7 @@ for s in shapes:
         c = 8
     x = torch.randn(n, h, w, c, device=dev).to(dt)
     wt = torch.randn(k, cin, r, r, device=dev) * 0.05
-    pc = ops.pack_conv(wt, torch.randn(k, device=dev), stride=st, pad=pad, cstore=c, dtype=dt)
+    pc = ops.pack_conv(wt, torch.randn(k, device=dev), stride=st, pad=pad, cstore=c, dtype=pdt)
     ho, wo = (h + 2 * pad - r) // st + 1, (w + 2 * pad - r) // st + 1
     resid = torch.randn(n, ho, wo, k, device=dev).to(dt) if res else None
     y = torch.empty(n, ho, wo, k, device=dev, dtype=dt)
