@@ -55,8 +55,10 @@ const char* seam_error_string(int code);
  */
 int seam_conv_kred(int C, int R, int S);           /* host helper: ceil(R*S*C / 32) * 32 */
 int seam_conv_rows_padded(int K);                  /* host helper: ceil(K / 64) * 64      */
-int seam_conv_tile(int M, int K);                  /* host helper: BM*1000+BN of the block tile the launcher
+int seam_conv_tile(int M, int K);                  /* host helper: BM*1000+BN of the block tile the fp32 launcher
                                                       picks for an [M x K] output (128 or 64 each) */
+int seam_conv_tile_prec(int prec, int M, int K);   /* same for prec 0 = fp32, 1 = fp16, 2 = split-bf16 (these two also
+                                                      have a 256x128 tile run by 8 waves) */
 
 /* Pack an OIHW weight [K,Cin,R,S] (PyTorch layout) into the kernel's slab layout
  * (rows_padded*kred floats; reduction chunks ordered (r, c-chunk, s); channels >= Cin zero-filled).

@@ -15,7 +15,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libseam_hip.so")
+LIB_PATH = os.environ.get("SEAM_LIB_PATH") or os.path.join(_HERE, "lib", "libseam_hip.so")   # env: kernel experiments only
 
 _p = C.c_void_p
 _i = C.c_int
@@ -29,6 +29,7 @@ SIGNATURES = {
     "seam_conv_kred": (_i, [_i, _i, _i]),
     "seam_conv_rows_padded": (_i, [_i]),
     "seam_conv_tile": (_i, [_i, _i]),
+    "seam_conv_tile_prec": (_i, [_i, _i, _i]),
     "seam_pack_conv_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_pack_conv_weight_bx3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -28,6 +28,7 @@
 //   blockIdx -> tile mapping is XCD-aware (consecutive tiles stay on one XCD's L2; bijective form).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -58,15 +59,16 @@ struct ConvArgs {
     int tiles_m, tiles_n;
 };
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
+template <typename T, int BM, int BN, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const ConvArgs p) {
     constexpr bool F16 = sizeof(T) == 2;
     constexpr int ES = (int)sizeof(T);
     constexpr int EPV = 16 / ES;                 // elements per 16-byte vector (4 / 8)
     constexpr int BKE = CHUNK_BYTES / ES;        // k elements per chunk (32 / 64)
-    constexpr int WM = BM / 2, WN = BN / 2;      // wave tile
+    constexpr int WM = BM / (NW / 2), WN = BN / 2;      // wave tile: NW waves as (NW/2) x 2
     constexpr int MT = WM / 32, NT = WN / 32;    // 32x32 MFMA tiles per wave
-    constexpr int AI = BM / 32, BI = BN / 32;    // 16-byte loads per thread per chunk
+    constexpr int RP = 8 * NW;                   // tile rows covered by one load pass of the block (8 lanes per row)
+    constexpr int AI = BM / RP, BI = BN / RP;    // 16-byte loads per thread per chunk
     constexpr int Q = (F16 ? 1 : 4) * MT * NT;   // MFMAs per k-slot (32 B of k per row)
 
     __shared__ __attribute__((aligned(16))) char As[2][BM * LDB];
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
     // any batch size (a 128-row tile never spans 2 GiB of input).
     const int nk = p.kred / BKE;
     const int lcol = tid & 7;     // which 16-byte vector of the chunk
-    const int lrow = tid >> 3;    // 0..31
+    const int lrow = tid >> 3;    // 0..RP-1
     const int HoWo = p.Ho * p.Wo;
     const int n_first = m0 / HoWo;
     const size_t img_elems = (size_t)p.H * p.W * p.C;
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
     int arow[AI], ahi[AI], awi[AI];      // byte offset of the (r=0,s=0,c=0) tap; top-left input coordinate
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RP * i;
         if (m < p.M) {
             const int n = m / HoWo;
             const int rm = m - n * HoWo;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
     }
     int brow[BI];
 #pragma unroll
-    for (int i = 0; i < BI; ++i) brow[i] = (lrow + 32 * i) * CHUNK_BYTES + lcol * 16;     // inside a [BN][128 B] slab
+    for (int i = 0; i < BI; ++i) brow[i] = (lrow + RP * i) * CHUNK_BYTES + lcol * 16;     // inside a [BN][128 B] slab
 
     // (r, s, c) of this thread's 16-byte vector inside the chunk being fetched, and its byte offset.
     // C >= one chunk: chunks are walked (r, c-chunk, s) -- exactly the order of the packed slabs.
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs p) {
         advance_k();
     };
     auto store_row = [&](const f32x4 (&ar)[AI], const f32x4 (&br)[BI], int buf, int r) {
-        if (r < AI) *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * r) * LDB + lcol * 16]) = ar[r];
-        else *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * (r - AI)) * LDB + lcol * 16]) = br[r - AI];
+        if (r < AI) *reinterpret_cast<f32x4*>(&As[buf][(lrow + RP * r) * LDB + lcol * 16]) = ar[r];
+        else *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + RP * (r - AI)) * LDB + lcol * 16]) = br[r - AI];
     };
 
     f32x16 acc[MT][NT];
@@ -366,12 +368,16 @@ __device__ __forceinline__ void split_bf16(const f32x4 v, u32x2& hi, u32x2& lo) 
     }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bx3(const ConvArgs p) {
+#ifndef SEAM_BX3_ABL
+#define SEAM_BX3_ABL 0      // kernel experiments: 1 no global loads, 2 no LDS stores, 4 no split VALU, 8 no barrier, 16 no frag reads
+#endif
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm_bx3(const ConvArgs p) {
     constexpr int ES = 4, EPV = 4, BKE = 32;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / (NW / 2), WN = BN / 2;
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int RP = 8 * NW;
+    constexpr int AI = BM / RP, BI = BN / RP;
     constexpr int Q = 3 * MT * NT;               // MFMAs per k-step (16 k-values)
     constexpr int PA = BM * 64 + 64;             // bytes of one A plane (+64: the lo plane starts on the other bank half)
     constexpr int PB = BN * 64 + 64;
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bx3(const ConvArgs p) {
     int arow[AI], ahi[AI], awi[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RP * i;
         if (m < p.M) {
             const int n = m / HoWo;
             const int rm = m - n * HoWo;
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bx3(const ConvArgs p) {
     }
     int brow[BI];
 #pragma unroll
-    for (int i = 0; i < BI; ++i) brow[i] = (lrow + 32 * i) * CHUNK_BYTES + lcol * 16;
+    for (int i = 0; i < BI; ++i) brow[i] = (lrow + RP * i) * CHUNK_BYTES + lcol * 16;
 
     int kc, kr, ks, tapoff;
     {
@@ -449,11 +455,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bx3(const ConvArgs p) {
     auto load_a = [&](f32x4 (&ar)[AI], int i) {
         const bool ok = (unsigned)(ahi[i] + kr) < (unsigned)p.H && (unsigned)(awi[i] + ks) < (unsigned)p.W && kr < p.R;
         const unsigned off = ok ? (unsigned)(arow[i] + tapoff) : kOob;
-        ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
+        if (!(SEAM_BX3_ABL & 1)) ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
     };
     auto load_b = [&](f32x4 (&br)[BI], int i) {
         const int so = uq < nk ? uq * slab_stride : (int)kOob;
-        br[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, brow[i], so, 0));
+        if (!(SEAM_BX3_ABL & 1)) br[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, brow[i], so, 0));
     };
     auto advance_k = [&]() {
         ++uq;
@@ -482,15 +488,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bx3(const ConvArgs p) {
     // LDS addresses of this thread's stores.  A: 4 floats -> 8 B of hi + 8 B of lo at bf16 index 4*lcol of the row;
     // B: 16 B of the packed row: lcol < 4 -> hi plane slot lcol, else lo plane slot lcol-4.
     auto store_row = [&](const f32x4 (&ar)[AI], const f32x4 (&br)[BI], int buf, int r) {
+        if (SEAM_BX3_ABL & 2) return;
         if (r < AI) {
-            const int row = lrow + 32 * r;
+            const int row = lrow + RP * r;
             const int off = row * 64 + ((((lcol >> 1) ^ (row >> 2)) & 3) << 4) + (lcol & 1) * 8;
             u32x2 hi, lo;
-            split_bf16(ar[r], hi, lo);
+            if (SEAM_BX3_ABL & 4) { hi[0] = __builtin_bit_cast(unsigned, ar[r][0]); hi[1] = __builtin_bit_cast(unsigned, ar[r][1]);
+                                    lo[0] = __builtin_bit_cast(unsigned, ar[r][2]); lo[1] = __builtin_bit_cast(unsigned, ar[r][3]); }
+            else split_bf16(ar[r], hi, lo);
             *reinterpret_cast<u32x2*>(&As[buf][off]) = hi;
             *reinterpret_cast<u32x2*>(&As[buf][PA + off]) = lo;
         } else {
-            const int row = lrow + 32 * (r - AI);
+            const int row = lrow + RP * (r - AI);
             const int off = (lcol >> 2) * PB + row * 64 + (((lcol ^ (row >> 2)) & 3) << 4);
             *reinterpret_cast<f32x4*>(&Bs[buf][off]) = br[r - AI];
         }
@@ -509,6 +518,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bx3(const ConvArgs p) {
     struct Frag { f32x4 ah[MT], al[MT], bh[NT], bl[NT]; };
     Frag f0, f1;
     auto read_frags = [&](Frag& f, int buf, int step) {
+        if (SEAM_BX3_ABL & 16) return;
         const int slot = 2 * step + (lane >> 5);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bx3(const ConvArgs p) {
             for (int r = 0; r < AI + BI; ++r)
                 if ((r * QS) / (AI + BI) == q) store_row(sta, stb, buf ^ 1, r);
             if (q == QS - 1) {
-                __syncthreads();
+                if (!(SEAM_BX3_ABL & 8)) __syncthreads();
                 read_frags(f0, buf ^ 1, 0);
             }
         }
@@ -694,20 +704,41 @@ int pack_weight(const float* w, void* w_packed, int K, int Cin, int R, int S, in
     return (int)hipGetLastError();
 }
 
-// Tile choice: the per-CU serialised MFMA work is ~ ceil(blocks / 256 CUs) * BM * BN, weighted by the
-// measured relative cost per FLOP of each tile shape (smaller tiles move more operand bytes per FLOP);
-// take the cheapest: launches that cannot fill the chip with 128-row tiles get 64-row / 64-col tiles.
-inline void choose_tile(int M, int K, int& best_bm, int& best_bn) {
+// Tile choice.  Cost model: ceil(blocks / 256 CUs) * BM * BN, weighted by the measured relative cost per FLOP of each
+// tile shape (smaller tiles move more operand bytes per FLOP).  What the probes say about the load path
+// (tools/l2_bw_probe.hip, tools/pmc_conv.sh): L2 hits stream at 48-55 B/clk/CU, L2 misses at 11.6; the conv kernels
+// sit at ~16 because 13-16 % of their 128-B requests miss the 4 MiB L2 (each input line is re-fetched once per tap row
+// r by tiles that touch it ~40 us apart), so halving the weight traffic with the 256x128 / 8-wave tile buys only
+// 2-6 % (fp16 / split-bf16) and nothing for exact fp32, which is MFMA-bound.  The lever that remains is staging the
+// input patch of a tile in LDS once per channel chunk and running all taps from it (next round).
+enum Prec { P_F32 = 0, P_F16 = 1, P_BX3 = 2 };
+
+inline int tile_weight(int prec, int bm, int bn) {
+    const int area = bm * bn;
+    if (prec == P_F32) return area == 256 * 128 ? 100 : area == 128 * 128 ? 100 : area == 64 * 64 ? 125 : 110;
+    return area == 256 * 128 ? (prec == P_BX3 ? 95 : 105) : area == 128 * 128 ? 100 : area == 64 * 64 ? 200 : 150;
+}
+
+inline void choose_tile(int prec, int M, int K, int& best_bm, int& best_bn) {
     const int rows = ((K + 63) / 64) * 64;
     const int slab = rows % 128 == 0 ? 128 : 64;
+    static const char* force = getenv("SEAM_CONV_TILE");           // kernel experiments: "256x128", "128x128", ...
+    if (force) {
+        int fm = 0, fn = 0;
+        if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 256 || fm == 128 || fm == 64) && (fn == 128 || fn == 64) &&
+            fn <= slab && (fm != 256 || fn == 128)) {
+            best_bm = fm; best_bn = fn;
+            return;
+        }
+    }
     long best_cost = -1;
     best_bm = 128;
     best_bn = slab;
-    for (int bm = 128; bm >= 64; bm -= 64)
+    for (int bm = 256; bm >= 64; bm >>= 1)
         for (int bn = slab; bn >= 64; bn -= 64) {
+            if (bm == 256 && (bn != 128 || prec == P_F32)) continue;       // 8-wave tile: 256x128 only; no gain for exact fp32
             const long nb = (long)((M + bm - 1) / bm) * (rows / bn);
-            const long w = (bm == 128 && bn == 128) ? 100 : (bm == 64 && bn == 64) ? 125 : 110;   // per-FLOP cost, %
-            const long cost = ((nb + 255) / 256) * bm * bn * w;
+            const long cost = ((nb + 255) / 256) * bm * bn * tile_weight(prec, bm, bn);
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bm = bm; best_bn = bn; }
         }
 }
@@ -731,15 +762,17 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     const int rows = ((K + 63) / 64) * 64;
     a.slab_bn = rows % 128 == 0 ? 128 : 64;
     int best_bm, best_bn;
-    choose_tile(a.M, K, best_bm, best_bn);
+    choose_tile(sizeof(T) == 2 ? P_F16 : P_F32, a.M, K, best_bm, best_bn);
     a.tiles_m = (a.M + best_bm - 1) / best_bm;
     a.tiles_n = rows / best_bn;
-    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    const dim3 grid(a.tiles_m * a.tiles_n);
     static const int dyn = getenv("SEAM_CONV_DYNLDS") ? atoi(getenv("SEAM_CONV_DYNLDS")) : 0;   // dev knob: occupancy experiments
-    if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 128>), grid, block, dyn, (hipStream_t)stream, a);
-    else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 64>), grid, block, dyn, (hipStream_t)stream, a);
-    else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 64, 128>), grid, block, dyn, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv_igemm<T, 64, 64>), grid, block, dyn, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (best_bm == 256) hipLaunchKernelGGL((conv_igemm<T, 256, 128, 8>), grid, dim3(512), dyn, st, a);
+    else if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 128, 4>), grid, dim3(256), dyn, st, a);
+    else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 64, 4>), grid, dim3(256), dyn, st, a);
+    else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 64, 128, 4>), grid, dim3(256), dyn, st, a);
+    else hipLaunchKernelGGL((conv_igemm<T, 64, 64, 4>), grid, dim3(256), dyn, st, a);
     return (int)hipGetLastError();
 }
 
@@ -760,14 +793,16 @@ int conv2d_bx3(const void* x, const void* w_packed, const float* scale, const fl
     const int rows = ((K + 63) / 64) * 64;
     a.slab_bn = rows % 128 == 0 ? 128 : 64;
     int best_bm, best_bn;
-    choose_tile(a.M, K, best_bm, best_bn);
+    choose_tile(P_BX3, a.M, K, best_bm, best_bn);
     a.tiles_m = (a.M + best_bm - 1) / best_bm;
     a.tiles_n = rows / best_bn;
-    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
-    if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm_bx3<128, 128>), grid, block, 0, (hipStream_t)stream, a);
-    else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm_bx3<128, 64>), grid, block, 0, (hipStream_t)stream, a);
-    else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm_bx3<64, 128>), grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv_igemm_bx3<64, 64>), grid, block, 0, (hipStream_t)stream, a);
+    const dim3 grid(a.tiles_m * a.tiles_n);
+    hipStream_t st = (hipStream_t)stream;
+    if (best_bm == 256) hipLaunchKernelGGL((conv_igemm_bx3<256, 128, 8>), grid, dim3(512), 0, st, a);
+    else if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm_bx3<128, 128, 4>), grid, dim3(256), 0, st, a);
+    else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm_bx3<128, 64, 4>), grid, dim3(256), 0, st, a);
+    else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm_bx3<64, 128, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_bx3<64, 64, 4>), grid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -778,9 +813,14 @@ extern "C" {
 int seam_conv_kred(int C, int R, int S) { return kred_of<float>(C, R, S); }
 int seam_conv_kred_f16(int C, int R, int S) { return kred_of<_Float16>(C, R, S); }
 int seam_conv_rows_padded(int K) { return ((K + 63) / 64) * 64; }
-int seam_conv_tile(int M, int K) {      // BM * 1000 + BN the launcher will pick for an [M x K] output
+int seam_conv_tile(int M, int K) {      // BM * 1000 + BN the fp32 launcher will pick for an [M x K] output
     int bm, bn;
-    choose_tile(M, K, bm, bn);
+    choose_tile(P_F32, M, K, bm, bn);
+    return bm * 1000 + bn;
+}
+int seam_conv_tile_prec(int prec, int M, int K) {      // same for prec 0 fp32 | 1 fp16 | 2 split-bf16
+    int bm, bn;
+    choose_tile(prec, M, K, bm, bn);
     return bm * 1000 + bn;
 }
 
