@@ -189,7 +189,9 @@ def main():
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     **({"mfma_passes_per_product": 3, "issued_frac": round(3 * achieved / peak, 4)} if args.dtype == "bf16x3" else {}),
-                    "traffic": pmc_traffic(dom), "algorithmic_bytes_per_launch": round(alg_bytes / n),
+                    "traffic": pmc_traffic(dom) if args.dtype == "f32" else None,
+                    "mfma_busy_frac_pmc": pmc_mfma_busy(dom) if args.dtype == "f32" else None,
+                    "algorithmic_bytes_per_launch": round(alg_bytes / n),
                     "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
                     "conv_ms_per_step": round(1e3 * sum(v[2] for v in per.values()), 3),
@@ -241,6 +243,17 @@ def pmc_traffic(kernel):
         d = json.load(open(files[-1]))
         return round((2.0 * d["FETCH_SIZE"][kernel]["avg_per_launch"] + d["WRITE_SIZE"][kernel]["avg_per_launch"]) * 1024)
     except (KeyError, ValueError, OSError):
+        return None
+
+
+def pmc_mfma_busy(kernel):
+    """Matrix-pipe busy fraction of `kernel` from the same committed PMC passes:
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES).  None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    try:
+        return json.load(open(files[-1]))["mfma_busy_frac"][kernel]
+    except (IndexError, KeyError, ValueError, OSError):
         return None
 
 

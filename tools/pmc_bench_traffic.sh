@@ -1,29 +1,42 @@
 #!/bin/bash
-# HBM traffic of the conv kernels during one bench run (GPU box): two separate --pmc passes
-# (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2 -- they do not fit together), per the guide.
-# Output: gpurun_out/pmc_traffic_<tag>.json  (per-launch averages, KB as reported by rocprofv3)
-TAG=${1:-r01}
+# HBM traffic + matrix-pipe utilisation of the conv kernels during one bench run (GPU box): separate --pmc passes
+# (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2 -- they do not fit together), per the guide; never mixed with trace domains
+# other than --kernel-trace.  usage: tools/pmc_bench_traffic.sh <tag> [bench flags...]
+# Output: gpurun_out/pmc_traffic_<tag>.json  (per-launch averages; FETCH/WRITE in KiB as reported by rocprofv3)
+TAG=${1:-r01}; shift
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>/tmp/pmc_$c.err || echo "pass $c failed"
+PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16")
+i=0
+for c in "${PASSES[@]}"; do
+  rm -rf /tmp/pmc_$i
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline "$@" > /dev/null 2>/tmp/pmc_$i.err || echo "pass $c failed"
+  i=$((i+1))
 done
 python3 - <<PY
-import csv, collections, json
+import csv, collections, json, re, os
 out = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f"/tmp/pmc_{c}/p_counter_collection.csv")):
-        name = r["Kernel_Name"]
-        key = None
-        for t in ("float", "_Float16"):
-            for bm in (128, 64):
-                for bn in (128, 64):
-                    if f"conv_igemm<{t}, {bm}, {bn}>" in name:
-                        key = f"conv_igemm<{t},{bm},{bn}>"
-        if key and r["Counter_Name"] == c:
-            agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
-    out[c] = {k: {"launches": v[0], "avg_per_launch": v[1] / v[0], "total": v[1]} for k, v in agg.items()}
+pat = re.compile(r"(conv_igemm(?:_bx3)?)<([^>]*)>")
+for i in range($i):
+    f = f"/tmp/pmc_{i}/p_counter_collection.csv"
+    if not os.path.exists(f):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0.0]))
+    for r in csv.DictReader(open(f)):
+        m = pat.search(r["Kernel_Name"])
+        if not m:
+            continue
+        args = [a.strip() for a in m.group(2).split(",")]
+        key = (f"{m.group(1)}<{args[0]},{args[1]}>" if m.group(1).endswith("bx3") else f"{m.group(1)}<{args[0]},{args[1]},{args[2]}>")
+        a = agg[r["Counter_Name"]][key]
+        a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    for c, d in agg.items():
+        out[c] = {k: {"launches": v[0], "avg_per_launch": v[1] / v[0], "total": v[1], "avg_us": v[2] / v[0]} for k, v in d.items()}
+if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "SQ_BUSY_CU_CYCLES" in out:
+    # matrix-pipe busy fraction while the CU is busy: MFMA busy cycles are counted per SIMD (4 per CU)
+    out["mfma_busy_frac"] = {k: round(out["SQ_VALU_MFMA_BUSY_CYCLES"][k]["total"] / (4.0 * out["SQ_BUSY_CU_CYCLES"][k]["total"]), 4)
+                             for k in out["SQ_VALU_MFMA_BUSY_CYCLES"] if k in out["SQ_BUSY_CU_CYCLES"]}
 json.dump(out, open("$R/gpurun_out/pmc_traffic_$TAG.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+print(json.dumps({k: v for k, v in out.items() if k in ("mfma_busy_frac",)}, indent=1))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    print(c, {k: round(v["avg_per_launch"]) for k, v in out.get(c, {}).items()})
 PY
