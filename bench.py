@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2",
                     help="c2 (default, the BASELINE metric's config): 10 x 800x800 frames, 32 ROI/frame, fp32; "
                          "c5: configs[4] per-GPU shape -- 30 x 1080x1920 frames, 64 ROI/frame (use with --dtype f16)")
+    ap.add_argument("--clips", type=int, default=8,
+                    help="clips batched per step on each GPU: their 10 x clips frames go through the extractor as one batch "
+                         "(BASELINE configs[2] batches 8 clips the same way); value counts clips/s.  --clips 1 = one clip "
+                         "per step (latency-oriented; 11 % lower throughput: the small pyramid levels cannot fill 256 CUs)")
     ap.add_argument("--dtype", choices=("f32", "f16", "bf16x3"), default="f32",
                     help="f32 (default, the headline: exact fp32 MFMA) | f16 (config-5 style fp16 MFMA, fp32 accumulate; "
                          "extractor + trunks in fp16, descriptors / NLB / match logits fp32)")
@@ -107,14 +111,15 @@ def main():
         model.set_compute_dtype(ops.BX3)
     log("weights on device; generating frames")
     ta = model.roi_heads.temporal_aggregator
-    frames = torch.from_numpy(synth.frames(rank, T, H, W)).to(dev)           # clip of this rank, resident
+    B = args.clips
+    frames = torch.cat([torch.from_numpy(synth.frames(rank * B + c, T, H, W)) for c in range(B)]).to(dev)   # this rank's clips, resident
     frame_list = list(frames.unbind(0))
     from seam_match_rcnn_amd.models.detection import resized_size
     rh, rw, _ = resized_size(H, W)                                           # ROIs live in the resized frame
     rois_np = synth.fixed_rois(R, rh, rw)
-    rois = [torch.from_numpy(rois_np).to(dev) for _ in range(T)]
-    types = torch.zeros(T * R, dtype=torch.int32)                            # all street ROIs (CPU, as the ref passes)
-    ids = torch.arange(R, dtype=torch.int64).repeat(T)                       # sequence id = ROI slot
+    rois = [torch.from_numpy(rois_np).to(dev) for _ in range(T * B)]
+    types = torch.zeros(B * T * R, dtype=torch.int32)                        # all street ROIs (CPU, as the ref passes)
+    ids = torch.cat([c * R + torch.arange(R, dtype=torch.int64).repeat(T) for c in range(B)])   # sequence id = (clip, ROI slot)
     lo, hi = retrieval.shard_range(G, rank, world)
     bank_shard = torch.from_numpy(synth.gallery(7, G)[lo:hi]).to(dev)        # this rank's product descriptors
     side = torch.cuda.Stream(device=dev) if world > 1 else None
@@ -166,7 +171,7 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     log(f"timed: {ms_per_step:.2f} ms/step")
-    value = world * args.steps / elapsed                                      # whole-job clips/s
+    value = world * B * args.steps / elapsed                                  # whole-job clips/s
 
     roofline = None
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -201,7 +206,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "c2":
         log("cpu baseline")
-        cpu = cpu_baseline(sd, frames.cpu(), rois_np, args.cpu_frames)
+        cpu = cpu_baseline(sd, frames[:T].cpu(), rois_np, args.cpu_frames)
         log("cpu baseline done")
 
     if rank == 0:
@@ -215,7 +220,7 @@ def main():
                                        f" full pipeline, fixed ROIs: {T} frames {H}x{W} -> ResNet-50-FPN + RPN head "
                                        f"-> RoIAlign 14x14 ({R} ROI/frame) -> mask head -> match trunk x2 -> SEAM NLB + "
                                        f"attention pool ({R} seq x {T}) -> pair logits vs {G}-product bank -> top-{TOPK}",
-                           "clips_per_step_per_gpu": 1, "hip_graph": bool(args.graph), "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
+                           "clips_per_step_per_gpu": B, "hip_graph": bool(args.graph), "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
                            "algorithmic_tflop_per_clip": round(FLOP_PER_CLIP / 1e12, 3),
                            "parallelism": f"dp{world} (clips sharded; product bank all-gathered over RCCL)"
                            if world > 1 else "single GPU"},

@@ -11,7 +11,8 @@ bash $R/tools/pmc_bench_traffic.sh $TAG > $O/${TAG}_pmc.log 2>&1
 python3 $R/bench.py --dtype bf16x3 --no-cpu-baseline > $O/${TAG}_bench_bf16x3.json 2>/dev/null
 python3 $R/bench.py --dtype f16 --no-cpu-baseline > $O/${TAG}_bench_f16.json 2>/dev/null
 python3 $R/bench.py --dtype f16 --workload c5 --no-cpu-baseline --steps 5 --warmup 1 > $O/${TAG}_bench_c5_f16.json 2>/dev/null
-python3 $R/bench.py --graph --no-cpu-baseline > $O/${TAG}_bench_graph.json 2>/dev/null
+python3 $R/bench.py --graph --clips 1 --no-cpu-baseline > $O/${TAG}_bench_graph.json 2>/dev/null
+python3 $R/bench.py --clips 1 --no-cpu-baseline > $O/${TAG}_bench_clips1.json 2>/dev/null
 bash $R/tools/pmc_bench_traffic.sh ${TAG}_bf16x3 --dtype bf16x3 > $O/${TAG}_pmc_bf16x3.log 2>&1
 python3 $R/tools/train_bench.py 8 10 > $O/${TAG}_train_bench.txt 2>/dev/null
 python3 $R/tools/full_forward_timing.py > $O/${TAG}_full_forward.txt 2>/dev/null
