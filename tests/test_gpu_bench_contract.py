@@ -1,0 +1,46 @@
+"""The driver's bench.py contract, checked end to end on the GPU box: one JSON line with the agreed keys, launched both
+plainly and through torch.distributed.run (the N>1 launcher, here with one rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config"}
+
+
+def run(cmd):
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_and_roofline_fields():
+    d = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--clips", "1", "--cpu-frames", "1"])
+    assert KEYS <= set(d)
+    assert d["metric"].startswith("video-clips/sec") and d["unit"] == "clips/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1.0 and abs(d["value"] * d["ms_per_step"] / 1e3 - d["config"]["clips_per_step_per_gpu"]) < 1e-2
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "clips/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 10 * c["value"]                # north_star's floor: >= 10x the same-host CPU path
+
+
+def test_bench_under_the_multi_gpu_launcher():
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+             "--master-port", "29533", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips", "2",
+             "--no-cpu-baseline", "--no-roofline"])
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["config"]["clips_per_step_per_gpu"] == 2 and d["value"] > 1.0
