@@ -11,9 +11,10 @@ dev = torch.device("cuda:0")
 model, sd = bench.build_model(dev)
 ta = model.roi_heads.temporal_aggregator
 T, R = bench.T, bench.R
-frames = list(torch.from_numpy(synth.frames(0, T, 800, 800)).to(dev).unbind(0))
-rois = [torch.from_numpy(synth.fixed_rois(R, 800, 800)).to(dev) for _ in range(T)]
-types = torch.zeros(T * R, dtype=torch.int32); ids = torch.arange(R).repeat(T)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8          # clips per step
+frames = list(torch.cat([torch.from_numpy(synth.frames(c, T, 800, 800)) for c in range(B)]).to(dev).unbind(0))
+rois = [torch.from_numpy(synth.fixed_rois(R, 800, 800)).to(dev) for _ in range(T * B)]
+types = torch.zeros(B * T * R, dtype=torch.int32); ids = torch.cat([c * R + torch.arange(R).repeat(T) for c in range(B)])
 def step():
     res, feats, rpn = model.forward_fixed_rois(frames, rois)
     rf = torch.cat([r["roi_features"] for r in res])
