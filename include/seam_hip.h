@@ -259,6 +259,24 @@ int seam_conv2d_bx3(const float* x, const void* w_packed, const float* scale, co
                     int stride, int pad, int relu, seam_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Winograd F(2x2,3x3) convolution, fp32 MFMA: the stride-1 3x3 layers of the same call sites as seam_conv2d_f32
+ * (ResNet-50 bottleneck 3x3s, FPN output convs, RPNHead conv [TV]; MaskRCNNHeads [TV]; MatchPredictor.conv_seq,
+ * models/match_head.py:50-60) with 2.25x fewer matrix-core issues.  Same contract as seam_conv2d_f32 with R = S = 3,
+ * stride = 1 (x NHWC [N,H,W,C], y NHWC [N,H+2*pad-2,W+2*pad-2,K], scale / shift / residual / relu identical);
+ * C must be a multiple of 8 and K of 32 (seam_wino_supported).  All arithmetic is fp32; results differ from
+ * seam_conv2d_f32 only by the rounding of the +/- transforms (~1e-6 relative to the output scale).
+ * u_packed: seam_wino_weight_floats(K, Cstore) floats from seam_pack_conv_weight_wino_f32 (U = G g Gt per (k, c),
+ * computed in fp64 and rounded once, stored in MFMA fragment order; mode 0 = forward weights [K,Cin,3,3],
+ * mode 2 = input-gradient weights as in seam_pack_conv_weight_f32). */
+int seam_wino_supported(int C, int K, int R, int S, int stride);
+long long seam_wino_weight_floats(int K, int Cstore);
+int seam_pack_conv_weight_wino_f32(const float* w, float* u_packed, int K, int Cin, int Cstore, int mode,
+                                   seam_stream_t stream);
+int seam_conv3x3_wino_f32(const float* x, const float* u_packed, const float* scale, const float* shift,
+                          const float* residual, float* y, int N, int H, int W, int C, int K, int pad, int relu,
+                          seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Gradient kernels of the match heads: the grad-enabled pass of the training loop,
  * stuffs/engine.py:120-121,158-168,183-185 -> MatchPredictor / TemporalAggregationNLB in .train()
  * (models/match_head.py:66-76,90-169,339).  fp32, fixed-order reductions (bit-reproducible).

@@ -57,9 +57,25 @@ class PackedConv:
     pad: int = 0
     Cin: int = 0                    # real (unpadded) input channels: algorithmic FLOP accounting
     dtype: object = F32             # operand precision of the packed weights: torch.float32 | torch.float16 | BX3
+    u: Optional[torch.Tensor] = None  # fp32 stride-1 3x3 layers: Winograd F(2x2,3x3) weights (seam_pack_conv_weight_wino_f32)
 
 
 BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
+
+
+# Exact-fp32 path: run the stride-1 3x3 layers through the Winograd F(2x2,3x3) kernel (csrc/seam_wino.hip).  All fp32
+# arithmetic; SEAM_WINOGRAD=0 keeps every layer on the implicit-GEMM kernel.
+import os as _os
+WINOGRAD = _os.environ.get("SEAM_WINOGRAD", "1") != "0"
+
+
+def _pack_wino(lib, weight: torch.Tensor, K: int, cin: int, cs: int, mode: int) -> Optional[torch.Tensor]:
+    if not lib.seam_wino_supported(cs, K, 3, 3, 1):
+        return None
+    u = torch.empty((int(lib.seam_wino_weight_floats(K, cs)),), dtype=F32, device=weight.device)
+    _native.check(lib.seam_pack_conv_weight_wino_f32(_ptr(weight), _ptr(u), K, cin, cs, mode, _stream()),
+                  "seam_pack_conv_weight_wino_f32")
+    return u
 
 
 # When set to a list, every conv launch is bracketed by HIP events on the launch stream and
@@ -91,11 +107,14 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
     epv = 8 if dtype == F16 else 4
     cs = cstore if cstore is not None else ((cin + epv - 1) // epv) * epv
     rows = lib.seam_conv_rows_padded(K)
+    u = None
     if dtype == F32:
         kred = lib.seam_conv_kred(cs, R, S)
         wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
         _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
                       "seam_pack_conv_weight_f32")
+        if mode == 0 and R == 3 and S == 3 and stride == 1:
+            u = _pack_wino(lib, weight, K, cin, cs, 0)
     elif dtype == BX3:
         kred = lib.seam_conv_kred(cs, R, S)
         wp = torch.empty((rows, kred), dtype=F32, device=weight.device)      # opaque: [32 hi | 32 lo] bf16 per 128-byte row-chunk
@@ -121,7 +140,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         shift = shift.contiguous()
     elif bias is not None:
         shift = bias.contiguous()
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype)
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u)
 
 
 def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0) -> PackedConv:
@@ -140,7 +159,8 @@ def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0) -> PackedConv:
     wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
     _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), cin, cout, R, S, cout, 2, _stream()),
                   "seam_pack_conv_weight_f32")
-    return PackedConv(wp, None, None, cin, cout, R, S, 1, R - 1 - pad_fwd, cout, F32)
+    u = _pack_wino(lib, weight, cin, cout, cout, 2) if R == 3 else None
+    return PackedConv(wp, None, None, cin, cout, R, S, 1, R - 1 - pad_fwd, cout, F32, u)
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int = 1, pad: int = 0) -> torch.Tensor:
@@ -272,7 +292,11 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = _native.lib()
-    if pc.dtype == F32:
+    wino = pc.dtype == F32 and pc.u is not None and WINOGRAD
+    if wino:
+        _native.check(lib.seam_conv3x3_wino_f32(_ptr(x), _ptr(pc.u), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
+                                                n, h, w, c, pc.K, pc.pad, int(relu), _stream()), "seam_conv3x3_wino_f32")
+    elif pc.dtype == F32:
         _native.check(lib.seam_conv2d_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                           n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, int(relu), _stream()),
                       "seam_conv2d_f32")
@@ -287,7 +311,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     if trace is not None:
         e1.record()
         tile = lib.seam_conv_tile_prec(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K)
-        if pc.dtype == BX3:
+        if wino:
+            variant = "conv3x3_wino<2>"
+        elif pc.dtype == BX3:
             variant = f"conv_igemm_bx3<{tile // 1000},{tile % 1000}>"
         else:
             variant = f"conv_igemm<{'float' if pc.dtype == F32 else '_Float16'},{tile // 1000},{tile % 1000}>"

@@ -1,0 +1,122 @@
+"""GPU parity of the Winograd F(2x2,3x3) kernel (csrc/seam_wino.hip) through the C ABI: vs the fp32 CPU oracle
+(torch conv2d = the ATen kernel the reference dispatches) and vs the implicit-GEMM kernel on the same inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import seam_match_rcnn_amd.synth as synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, shape, name="x"):
+    return torch.from_numpy(synth.normal(synth.stream_id(seed, name), shape))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import seam_match_rcnn_amd.ops as ops
+    return ops
+
+
+WINO_CASES = [
+    # N, C, H, W, K, pad, bn, res, relu
+    (2, 64, 20, 24, 64, 1, True, False, True),        # layer1 3x3
+    (1, 128, 17, 19, 128, 1, True, False, True),      # odd map: half-filled edge tiles
+    (2, 256, 13, 13, 256, 1, False, False, True),     # RPN head on the pool level
+    (1, 256, 25, 32, 256, 1, False, False, False),    # FPN output conv (bias only)
+    (3, 256, 14, 14, 256, 1, False, False, True),     # mask head
+    (3, 256, 14, 14, 256, 0, False, False, True),     # match trunk: valid 3x3, 14 -> 12
+    (2, 256, 8, 8, 1024, 0, False, False, True),      # match trunk last conv, 8 -> 6
+    (1, 512, 7, 9, 512, 1, True, True, True),         # layer4-like with a residual
+    (1, 8, 5, 70, 32, 1, False, False, False),        # smallest legal channels, wide patch (several blocks per row)
+    (1, 64, 3, 3, 32, 0, False, False, False),        # single output pixel
+    (2, 24, 37, 41, 96, 1, False, True, False),       # C, K not powers of two; residual without ReLU
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_wino_vs_oracle(ops, case):
+    n, c, h, w, k, pad, bn, res, relu = case
+    x = rnd(31, (n, c, h, w))
+    wt = rnd(32, (k, c, 3, 3), "w") * (1.0 / math.sqrt(c * 9))
+    bias = None if bn else rnd(33, (k,), "b") * 0.1
+    ref = F.conv2d(x, wt, bias, 1, pad)
+    bnp = None
+    if bn:
+        bw = torch.from_numpy(synth.uniform(synth.stream_id(34, "bw"), (k,), 0.5, 1.5))
+        bb, rm = rnd(35, (k,), "bb") * 0.1, rnd(36, (k,), "rm") * 0.1
+        rv = torch.from_numpy(synth.uniform(synth.stream_id(37, "rv"), (k,), 0.5, 1.5))
+        bnp = (bw, bb, rm, rv)
+        sc = bw * (rv + 1e-5).rsqrt()
+        ref = ref * sc[None, :, None, None] + (bb - rm * sc)[None, :, None, None]
+    resid = None
+    if res:
+        resid = rnd(38, ref.shape, "res")
+        ref = ref + resid
+    if relu:
+        ref = F.relu(ref)
+    d = torch.device("cuda:0")
+    pc = ops.pack_conv(wt.to(d), None if bias is None else bias.to(d), None if bnp is None else tuple(t.to(d) for t in bnp),
+                       stride=1, pad=pad)
+    assert pc.u is not None, "layer should be Winograd-eligible"
+    xin = nhwc(x).to(d)
+    rin = None if resid is None else nhwc(resid).to(d)
+    saved = ops.WINOGRAD
+    try:
+        ops.WINOGRAD = True
+        yw = ops.conv2d(xin, pc, relu, rin)
+        ops.WINOGRAD = False
+        yd = ops.conv2d(xin, pc, relu, rin)
+    finally:
+        ops.WINOGRAD = saved
+    torch.cuda.synchronize()
+    yw, yd = yw.permute(0, 3, 1, 2).cpu(), yd.permute(0, 3, 1, 2).cpu()
+    scale = float(ref.abs().max())
+    # tolerance written here: 1e-3 relative (north_star) + 1e-4 of the tensor's max; measured: ~1e-6 of the max
+    tol = 1e-3 * ref.abs() + 1e-4 * scale
+    assert bool(((yw - ref).abs() <= tol).all()), f"winograd vs oracle: max err {float((yw - ref).abs().max()):.3e} (scale {scale:.3e})"
+    assert float((yw - yd).abs().max()) <= 2e-5 * scale, f"winograd vs implicit GEMM: {float((yw - yd).abs().max()):.3e} (scale {scale:.3e})"
+
+
+def test_wino_dgrad_weights(ops):
+    """mode 2 pack (input-gradient weights: taps rotated, channels swapped) with the ReLU-mask epilogue (relu = 2)."""
+    d = torch.device("cuda:0")
+    wt = rnd(41, (64, 96, 3, 3), "w") / math.sqrt(96 * 9)        # forward conv 96 -> 64
+    dy = rnd(42, (2, 64, 12, 10), "dy")
+    act = rnd(43, (2, 96, 12, 10), "act")
+    ref = F.conv_transpose2d(dy, wt, None, 1, 1) * (act > 0)
+    pc = ops.pack_conv_dgrad(wt.to(d), pad_fwd=1)
+    assert pc.u is not None
+    saved = ops.WINOGRAD
+    try:
+        ops.WINOGRAD = True
+        got = ops.conv2d(nhwc(dy).to(d), pc, 2, nhwc(act).to(d))
+    finally:
+        ops.WINOGRAD = saved
+    got = got.permute(0, 3, 1, 2).cpu()
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def test_wino_batch_invariance_and_determinism(ops):
+    """Each image's result is independent of the batch it rides in, and repeat launches are bit-identical."""
+    d = torch.device("cuda:0")
+    x = nhwc(rnd(51, (5, 256, 26, 30))).to(d)
+    wt = (rnd(52, (256, 256, 3, 3), "w") / 48.0).to(d)
+    pc = ops.pack_conv(wt, None, stride=1, pad=1)
+    saved = ops.WINOGRAD
+    try:
+        ops.WINOGRAD = True
+        y5 = ops.conv2d(x, pc, True)
+        y5b = ops.conv2d(x, pc, True)
+        y1 = ops.conv2d(x[3:4].contiguous(), pc, True)
+    finally:
+        ops.WINOGRAD = saved
+    assert torch.equal(y5, y5b)
+    assert torch.equal(y5[3:4], y1)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Winograd F(2x2,3x3) kernel vs the implicit-GEMM kernel on the path's stride-1 3x3 shapes (GPU box).
+usage: wino_bench.py [N,H,W,C,K,pad ...]     env SEAM_WINO_MT=1|2 picks the tile variant"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from seam_match_rcnn_amd import ops
+
+DEFAULT = ["80,200,200,256,256,1", "80,100,100,256,256,1", "80,50,50,256,256,1", "80,25,25,256,256,1", "80,13,13,256,256,1",
+           "80,200,200,64,64,1", "80,100,100,128,128,1", "80,50,50,256,256,1", "80,25,25,512,512,1",
+           "2560,14,14,256,256,1", "2560,14,14,256,256,0", "2560,12,12,256,256,0", "2560,10,10,256,256,0", "2560,8,8,256,1024,0",
+           "10,200,200,256,256,1"]
+shapes = [a for a in sys.argv[1:] if not a.startswith("--")] or DEFAULT
+dev = torch.device("cuda:0")
+print(f"{'N,H,W,C,K,pad':>24} {'direct us':>10} {'TF/s':>7} {'wino us':>10} {'TF/s(alg)':>9} {'x':>6} {'maxdiff/scale':>13}")
+for s in shapes:
+    n, h, w, c, k, pad = map(int, s.split(","))
+    x = torch.randn(n, h, w, c, device=dev)
+    wt = torch.randn(k, c, 3, 3, device=dev) * (1.0 / (3 * c ** 0.5))
+    pc = ops.pack_conv(wt, torch.randn(k, device=dev), stride=1, pad=pad)
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    y = [torch.empty(n, ho, wo, k, device=dev) for _ in range(2)]
+    us = []
+    for wi in (0, 1):
+        ops.WINOGRAD = bool(wi)
+        for _ in range(2):
+            ops.conv2d(x, pc, True, out=y[wi])
+        torch.cuda.synchronize()
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.conv2d(x, pc, True, out=y[wi])
+        e1.record(); torch.cuda.synchronize()
+        us.append(e0.elapsed_time(e1) * 1e3 / reps)
+    fl = 2.0 * n * ho * wo * k * 9 * c
+    diff = float((y[0] - y[1]).abs().max()) / float(y[0].abs().max())
+    print(f"{s:>24} {us[0]:10.1f} {fl/us[0]/1e6:7.1f} {us[1]:10.1f} {fl/us[1]/1e6:9.1f} {us[0]/us[1]:6.2f} {diff:13.2e}")
