@@ -270,6 +270,11 @@ int seam_conv2d_bx3(const float* x, const void* w_packed, const float* scale, co
  * mode 2 = input-gradient weights as in seam_pack_conv_weight_f32). */
 int seam_wino_supported(int C, int K, int R, int S, int stride);
 long long seam_wino_weight_floats(int K, int Cstore);
+int seam_wino_slot_fill_pct(int N, int H, int W, int C, int K, int pad);   /* host helper: % of the launch's 2x2-tile slots
+                                                                             that hold real output (the caller's switch
+                                                                             between this kernel and seam_conv2d_f32) */
+int seam_wino_tile_variant(int N, int H, int W, int C, int K, int pad);   /* host helper: MT of the conv3x3_wino<MT>
+                                                                            kernel the launcher picks (32*MT tiles per block) */
 int seam_pack_conv_weight_wino_f32(const float* w, float* u_packed, int K, int Cin, int Cstore, int mode,
                                    seam_stream_t stream);
 int seam_conv3x3_wino_f32(const float* x, const float* u_packed, const float* scale, const float* shift,

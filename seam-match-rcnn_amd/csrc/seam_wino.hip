@@ -44,6 +44,7 @@ struct WinoArgs {
     int Ho, Wo, pad, relu;
     int TX, TY;           // tiles per block patch (TX*TY <= 32*MT)
     int bx, by;           // blocks per image along x / y
+    int G;                // images per block (small maps: the whole tile grid of G images shares one block; bx = by = 1)
     int tiles_n;          // K / 32
     int nchunks;          // C / 8
 };
@@ -75,21 +76,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
     const int tm = tile / p.tiles_n;
     const int tn = tile - tm * p.tiles_n;
     const int per_img = p.bx * p.by;
-    const int n_img = tm / per_img;
-    const int rb = tm - n_img * per_img;
+    const int n_img = (tm / per_img) * p.G;                // first image of this block
+    const int rb = tm - (tm / per_img) * per_img;
+    const int n_here = min(p.G, p.N - n_img);              // images of this block that exist
     const int byi = rb / p.bx;
     const int bxi = rb - byi * p.bx;
     const int ty0 = byi * p.TY, tx0 = bxi * p.TX;          // first tile of this block
     const int iy0 = 2 * ty0 - p.pad, ix0 = 2 * tx0 - p.pad; // top-left input pixel of the raw patch
 
     const int PW = 2 * p.TX + 2, PH = 2 * p.TY + 2;
-    const int NPIX = PW * PH;
+    const int NPIX1 = PW * PH;                             // patch pixels per image
+    const int NPIX = NPIX1 * p.G;
+    const int tpi = p.TX * p.TY;                           // tile slots per image
     const int HS = p.TX + 1;                               // 16-byte entries per (patch row, x parity)
 
     // ---- raw patch loader -----------------------------------------------------------------------------------------
     const size_t img_bytes = (size_t)p.H * p.W * p.C * 4;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.x + (size_t)n_img * img_bytes), 0, (int)img_bytes, 0x00020000);
+        (void*)((const char*)p.x + (size_t)n_img * img_bytes), 0, (int)(img_bytes * n_here), 0x00020000);
     unsigned goff[NI];
     int loff[NI];
 #pragma unroll
@@ -98,12 +102,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
         const int half = idx & 1;
         const int pix = idx >> 1;
         const bool ok = pix < NPIX;
-        const int py = pix / PW;
-        const int px = pix - py * PW;
+        const int g = pix / NPIX1;
+        const int lp = pix - g * NPIX1;
+        const int py = lp / PW;
+        const int px = lp - py * PW;
         const int gy = iy0 + py, gx = ix0 + px;
-        const bool inb = ok && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        goff[i] = inb ? (unsigned)(((gy * p.W + gx) * p.C + half * 4) * 4) : kOob;
-        loff[i] = ok ? (half * NPIX + (py * 2 + (px & 1)) * HS + (px >> 1)) * 16 : 2 * NPIXMAX * 16;
+        const bool inb = ok && g < n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        goff[i] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + half * 4) * 4) : kOob;
+        loff[i] = ok ? (half * NPIX + g * NPIX1 + (py * 2 + (px & 1)) * HS + (px >> 1)) * 16 : 2 * NPIXMAX * 16;
     }
     const int last_chunk = p.nchunks - 1;
     f32x4 rset[2][NI];
@@ -139,10 +145,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int id = mt * 32 + (lane & 31);
-        if (id >= p.TX * p.TY) id = 0;                     // idle tile slots read tile 0 (results are never stored)
-        const int tyl = id / p.TX;
-        const int txl = id - tyl * p.TX;
-        rbase[mt] = ((lane >> 5) * NPIX + 4 * tyl * HS + txl) * 16;
+        if (id >= tpi * p.G) id = 0;                       // idle tile slots read tile 0 (results are never stored)
+        const int g = id / tpi;
+        const int li = id - g * tpi;
+        const int tyl = li / p.TX;
+        const int txl = li - tyl * p.TX;
+        rbase[mt] = ((lane >> 5) * NPIX + g * NPIX1 + 4 * tyl * HS + txl) * 16;
     }
     const int oa = ra * row_bytes, ob = rbw * row_bytes;
     const int c1 = HS * 16;                                 // column offsets: j=0: 0, j=1: HS*16, j=2: 16, j=3: HS*16+16
@@ -292,9 +300,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
     // ---- epilogue: output transform + scale/shift (+ residual, ReLU) ------------------------------------------------
     const size_t out_img = (size_t)p.Ho * p.Wo * p.K * 4;
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((char*)p.y + (size_t)n_img * out_img), 0, (int)out_img, 0x00020000);
+        (void*)((char*)p.y + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)(p.res ? p.res : p.y) + (size_t)n_img * out_img), 0, (int)out_img, 0x00020000);
+        (void*)((const char*)(p.res ? p.res : p.y) + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
     const int et = tid >> 3;          // tile row of the exchange this thread finishes
     const int n4 = tid & 7;
     const int ncol = tn * 32 + n4 * 4;
@@ -313,9 +321,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
         }
         __syncthreads();
         const int id = mt * 32 + et;
-        const bool tile_ok = id < p.TX * p.TY;
-        const int tyl = id / p.TX;
-        const int txl = id - tyl * p.TX;
+        const int g = id / tpi;
+        const int li = id - g * tpi;
+        const bool tile_ok = g < n_here;
+        const int tyl = li / p.TX;
+        const int txl = li - tyl * p.TX;
         const int oy = 2 * (ty0 + tyl), ox = 2 * (tx0 + txl);
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) {
                 const bool ok = tile_ok && (oy + aa) < p.Ho && (ox + bb) < p.Wo;
-                const unsigned off = ok ? (unsigned)((((oy + aa) * p.Wo + ox + bb) * p.K + ncol) * 4) : kOob;
+                const unsigned off = ok ? (unsigned)(((((g * p.Ho + oy + aa) * p.Wo) + ox + bb) * p.K + ncol) * 4) : kOob;
                 f32x4 v = yv[aa] * sc + sh;
                 if (p.res) {
                     const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
@@ -399,19 +409,39 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-// Patch shape: minimise the number of blocks per image (then the raw patch size) over TX*TY <= 32*MT.
-inline void choose_patch(int tiles_x, int tiles_y, int mt, int& TX, int& TY) {
+// Patch shape for one tile variant: minimise the number of blocks (then the raw patch size) over TX*TY <= 32*MT; maps
+// whose whole tile grid fits several times into a block share it between G images (ROI tiles of the heads).
+struct Patch { int TX, TY, G, bx, by; long blocks; };   // blocks: per n-tile, for N images
+
+inline Patch choose_patch(int N, int tiles_x, int tiles_y, int mt, size_t in_img_bytes, size_t out_img_bytes) {
     const int cap = 32 * mt, npixmax = mt == 2 ? 384 : 208;
-    long best = -1;
-    TX = 1; TY = 1;
+    Patch best;
+    best.blocks = -1;
+    const int whole = (2 * tiles_x + 2) * (2 * tiles_y + 2);
+    if (tiles_x * tiles_y <= cap && whole <= npixmax) {          // whole images per block
+        int g = cap / (tiles_x * tiles_y);
+        if (g * whole > npixmax) g = npixmax / whole;
+        while (g > 1 && ((size_t)g * in_img_bytes >= kOob || (size_t)g * out_img_bytes >= kOob)) --g;
+        if (g > N) g = N;
+        best.TX = tiles_x; best.TY = tiles_y; best.G = g; best.bx = best.by = 1;
+        best.blocks = (N + g - 1) / g;
+        return best;
+    }
+    long best_cost = -1;
     for (int ty = 1; ty <= cap; ++ty)
         for (int tx = 1; tx * ty <= cap; ++tx) {
             const int npix = (2 * tx + 2) * (2 * ty + 2);
             if (npix > npixmax) continue;
             const long nb = (long)((tiles_x + tx - 1) / tx) * ((tiles_y + ty - 1) / ty);
             const long cost = nb * 4096 + npix;
-            if (best < 0 || cost < best) { best = cost; TX = tx; TY = ty; }
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best.TX = tx; best.TY = ty; best.G = 1;
+                best.bx = (tiles_x + tx - 1) / tx; best.by = (tiles_y + ty - 1) / ty;
+                best.blocks = nb * N;
+            }
         }
+    return best;
 }
 
 inline bool wino_ok(int C, int K, int R, int S, int stride) { return R == 3 && S == 3 && stride == 1 && C % 8 == 0 && K % 32 == 0 && C >= 8; }
@@ -433,25 +463,57 @@ int seam_pack_conv_weight_wino_f32(const float* w, float* u_packed, int K, int C
     return (int)hipGetLastError();
 }
 
-int seam_conv3x3_wino_f32(const float* x, const float* u_packed, const float* scale, const float* shift, const float* residual,
-                          float* y, int N, int H, int W, int C, int K, int pad, int relu, void* stream) {
+// Launch plan shared by the launcher and the profitability query.
+static int wino_plan(WinoArgs& a, int N, int H, int W, int C, int K, int pad, int& mt, long& blocks) {
     if (!wino_ok(C, K, 3, 3, 1) || N <= 0) return (int)hipErrorInvalidValue;
-    WinoArgs a;
-    a.x = x; a.u = u_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K;
-    a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2; a.pad = pad; a.relu = relu;
+    a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2; a.pad = pad;
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
     if ((size_t)H * W * C * 4 >= kOob || (size_t)a.Ho * a.Wo * K * 4 >= kOob) return (int)hipErrorInvalidValue;
     const int tiles_x = (a.Wo + 1) / 2, tiles_y = (a.Ho + 1) / 2;
     static const int force_mt = getenv("SEAM_WINO_MT") ? atoi(getenv("SEAM_WINO_MT")) : 0;    // kernel experiments
-    const int mt = force_mt == 1 || force_mt == 2 ? force_mt : 2;
-    choose_patch(tiles_x, tiles_y, mt, a.TX, a.TY);
-    a.bx = (tiles_x + a.TX - 1) / a.TX;
-    a.by = (tiles_y + a.TY - 1) / a.TY;
+    const size_t in_b = (size_t)H * W * C * 4, out_b = (size_t)a.Ho * a.Wo * K * 4;
+    const Patch p2 = choose_patch(N, tiles_x, tiles_y, 2, in_b, out_b), p1 = choose_patch(N, tiles_x, tiles_y, 1, in_b, out_b);
     a.tiles_n = K / 32;
     a.nchunks = C / 8;
-    const long blocks = (long)N * a.bx * a.by * a.tiles_n;
+    // Tile variant: a 64-tile block costs ~1.9x a 32-tile block (same weight stream, twice the MFMAs); take the 32-tile
+    // variant when it wastes fewer slots, or when the 64-tile grid could not fill the chip twice.
+    mt = (p1.blocks * 100 < p2.blocks * 190 || p2.blocks * a.tiles_n < 1024) ? 1 : 2;
+    if (force_mt == 1 || force_mt == 2) mt = force_mt;
+    const Patch& pp = mt == 2 ? p2 : p1;
+    a.TX = pp.TX; a.TY = pp.TY; a.G = pp.G; a.bx = pp.bx; a.by = pp.by;
+    blocks = pp.blocks * a.tiles_n;
     if (blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    return 0;
+}
+
+/* Percentage of the block's tile slots that hold real output tiles (100 = no waste).  The Winograd kernel issues
+ * 2.25x fewer MFMAs than the implicit GEMM, so it wins when this is above ~50 (ops.conv2d uses it to pick). */
+int seam_wino_slot_fill_pct(int N, int H, int W, int C, int K, int pad) {
+    WinoArgs a;
+    int mt;
+    long blocks;
+    if (wino_plan(a, N, H, W, C, K, pad, mt, blocks)) return 0;
+    const double tiles = (double)N * ((a.Wo + 1) / 2) * ((a.Ho + 1) / 2) * a.tiles_n;
+    return (int)(100.0 * tiles / ((double)blocks * 32 * mt));
+}
+
+int seam_wino_tile_variant(int N, int H, int W, int C, int K, int pad) {     // MT of conv3x3_wino<MT> the launcher picks (0: unsupported)
+    WinoArgs a;
+    int mt;
+    long blocks;
+    return wino_plan(a, N, H, W, C, K, pad, mt, blocks) ? 0 : mt;
+}
+
+int seam_conv3x3_wino_f32(const float* x, const float* u_packed, const float* scale, const float* shift, const float* residual,
+                          float* y, int N, int H, int W, int C, int K, int pad, int relu, void* stream) {
+    WinoArgs a;
+    int mt;
+    long blocks;
+    const int rc = wino_plan(a, N, H, W, C, K, pad, mt, blocks);
+    if (rc) return rc;
+    a.x = x; a.u = u_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.relu = relu;
     hipStream_t st = (hipStream_t)stream;
     if (mt == 2) hipLaunchKernelGGL((conv3x3_wino<2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wino<1>), dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -78,6 +78,18 @@ def _pack_wino(lib, weight: torch.Tensor, K: int, cin: int, cs: int, mode: int) 
     return u
 
 
+WINO_MIN_FILL = int(_os.environ.get("SEAM_WINO_MIN_FILL", "55"))    # % of tile slots in use below which the implicit GEMM wins
+_WINO_FILL = {}
+
+
+def _wino_pays(lib, n, h, w, c, k, pad) -> bool:
+    key = (n, h, w, c, k, pad)
+    f = _WINO_FILL.get(key)
+    if f is None:
+        f = _WINO_FILL[key] = int(lib.seam_wino_slot_fill_pct(n, h, w, c, k, pad))
+    return f >= WINO_MIN_FILL
+
+
 # When set to a list, every conv launch is bracketed by HIP events on the launch stream and
 # (variant, algorithmic_flops, start_event, end_event) is appended (bench.py's roofline leg).
 CONV_TRACE = None
@@ -292,7 +304,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = _native.lib()
-    wino = pc.dtype == F32 and pc.u is not None and WINOGRAD
+    wino = pc.dtype == F32 and pc.u is not None and WINOGRAD and _wino_pays(lib, n, h, w, c, pc.K, pc.pad)
     if wino:
         _native.check(lib.seam_conv3x3_wino_f32(_ptr(x), _ptr(pc.u), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                                 n, h, w, c, pc.K, pc.pad, int(relu), _stream()), "seam_conv3x3_wino_f32")
@@ -312,7 +324,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         e1.record()
         tile = lib.seam_conv_tile_prec(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K)
         if wino:
-            variant = "conv3x3_wino<2>"
+            variant = f"conv3x3_wino<{lib.seam_wino_tile_variant(n, h, w, c, pc.K, pc.pad)}>"
         elif pc.dtype == BX3:
             variant = f"conv_igemm_bx3<{tile // 1000},{tile % 1000}>"
         else:

@@ -32,7 +32,13 @@ def test_bench_line_and_roofline_fields():
     assert d["value"] > 1.0 and abs(d["value"] * d["ms_per_step"] / 1e3 - d["config"]["clips_per_step_per_gpu"]) < 1e-2
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] > 0.3
+    if r["kernel"].startswith("conv3x3_wino"):
+        # `achieved` counts ALGORITHMIC FLOPs (2*M*K*9*C); Winograd F(2x2,3x3) issues 2.25x fewer, so frac may pass 1.0
+        # while the issued-MFMA fraction stays below the peak
+        assert abs(r["mfma_issued_frac"] - r["frac"] / 2.25) < 1e-3 and r["mfma_issued_frac"] < 1.0
+    else:
+        assert r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "clips/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c

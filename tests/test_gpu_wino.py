@@ -22,7 +22,10 @@ def nhwc(x):
 @pytest.fixture(scope="module")
 def ops():
     import seam_match_rcnn_amd.ops as ops
-    return ops
+    saved = ops.WINO_MIN_FILL
+    ops.WINO_MIN_FILL = 0            # force the Winograd kernel on every eligible shape, however poorly it fills its tiles
+    yield ops
+    ops.WINO_MIN_FILL = saved
 
 
 WINO_CASES = [
@@ -38,6 +41,9 @@ WINO_CASES = [
     (1, 8, 5, 70, 32, 1, False, False, False),        # smallest legal channels, wide patch (several blocks per row)
     (1, 64, 3, 3, 32, 0, False, False, False),        # single output pixel
     (2, 24, 37, 41, 96, 1, False, True, False),       # C, K not powers of two; residual without ReLU
+    (7, 256, 10, 10, 256, 0, False, False, True),     # 4x4 tiles per image: several images share a block, last block ragged
+    (11, 256, 8, 8, 64, 0, False, True, True),        # 3x3 tiles per image, 6 (or 3) images per block, residual
+    (5, 64, 12, 12, 64, 0, False, False, False),      # 5x5 tiles per image, 2 images per block, odd image count
 ]
 
 

@@ -15,7 +15,7 @@ done
 python3 - <<PY
 import csv, collections, json, re, os
 out = {}
-pat = re.compile(r"(conv_igemm(?:_bx3)?)<([^>]*)>")
+pat = re.compile(r"(conv_igemm(?:_bx3)?|conv3x3_wino)<([^>]*)>")
 for i in range($i):
     f = f"/tmp/pmc_{i}/p_counter_collection.csv"
     if not os.path.exists(f):
@@ -26,7 +26,8 @@ for i in range($i):
         if not m:
             continue
         args = [a.strip() for a in m.group(2).split(",")]
-        key = (f"{m.group(1)}<{args[0]},{args[1]}>" if m.group(1).endswith("bx3") else f"{m.group(1)}<{args[0]},{args[1]},{args[2]}>")
+        key = (f"{m.group(1)}<{args[0]}>" if m.group(1).endswith("wino") else
+               f"{m.group(1)}<{args[0]},{args[1]}>" if m.group(1).endswith("bx3") else f"{m.group(1)}<{args[0]},{args[1]},{args[2]}>")
         a = agg[r["Counter_Name"]][key]
         a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     for c, d in agg.items():

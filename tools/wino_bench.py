@@ -4,7 +4,8 @@ usage: wino_bench.py [N,H,W,C,K,pad ...]     env SEAM_WINO_MT=1|2 picks the tile
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from seam_match_rcnn_amd import ops
+from seam_match_rcnn_amd import ops, _native
+ops.WINO_MIN_FILL = 0
 
 DEFAULT = ["80,200,200,256,256,1", "80,100,100,256,256,1", "80,50,50,256,256,1", "80,25,25,256,256,1", "80,13,13,256,256,1",
            "80,200,200,64,64,1", "80,100,100,128,128,1", "80,50,50,256,256,1", "80,25,25,512,512,1",
@@ -35,4 +36,5 @@ for s in shapes:
         us.append(e0.elapsed_time(e1) * 1e3 / reps)
     fl = 2.0 * n * ho * wo * k * 9 * c
     diff = float((y[0] - y[1]).abs().max()) / float(y[0].abs().max())
-    print(f"{s:>24} {us[0]:10.1f} {fl/us[0]/1e6:7.1f} {us[1]:10.1f} {fl/us[1]/1e6:9.1f} {us[0]/us[1]:6.2f} {diff:13.2e}")
+    fill = _native.lib().seam_wino_slot_fill_pct(n, h, w, c, k, pad)
+    print(f"{s:>24} {us[0]:10.1f} {fl/us[0]/1e6:7.1f} {us[1]:10.1f} {fl/us[1]/1e6:9.1f} {us[0]/us[1]:6.2f} {diff:13.2e} fill {fill}%")
