@@ -25,7 +25,7 @@ class TrunkFunction(torch.autograd.Function):
         ws, bs = (w0, w1, w2, w3), (b0, b1, b2, b3)
         acts = [ops.nchw_to_nhwc(x.detach().to(F32))]
         for w, b in zip(ws, bs):                                 # 14 -> 12 -> 10 -> 8 -> 6
-            acts.append(ops.conv2d(acts[-1], ops.pack_conv(w, b), relu=True))
+            acts.append(ops.conv2d(acts[-1], ops.pack_conv(w, b, wino=False), relu=True))
         pool = ops.avgpool(acts[-1])                             # its ReLU is the identity on a mean of ReLU outputs
         lin = ops.linear(pool, ops.pack_conv(lw, lb))
         if bn_train:
@@ -57,9 +57,9 @@ class TrunkFunction(torch.autograd.Function):
             dws[l] = ops.conv_wgrad(acts[l], dy, 3, 3)
             dbs[l] = ops.colsum(dy)
             if l > 0:                                             # input gradient, masked by the ReLU of the producer
-                dy = ops.conv2d(dy, ops.pack_conv_dgrad(weights[l]), relu=2, residual=acts[l])
+                dy = ops.conv2d(dy, ops.pack_conv_dgrad(weights[l], wino=False), relu=2, residual=acts[l])
             elif ctx.needs_input_grad[0]:
-                dx = ops.nhwc_to_nchw(ops.conv2d(dy, ops.pack_conv_dgrad(weights[0])))
+                dx = ops.nhwc_to_nchw(ops.conv2d(dy, ops.pack_conv_dgrad(weights[0], wino=False)))
         return (dx, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dws[3], dbs[3], dlw, dlb, dgamma, dbeta,
                 None, None, None, None, None)
 

@@ -97,12 +97,14 @@ CONV_TRACE = None
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None, *, stride: int = 1,
               pad: int = 0, cstore: Optional[int] = None, transposed2x2: bool = False,
-              bn_eps: float = 1e-5, dtype: torch.dtype = F32) -> PackedConv:
+              bn_eps: float = 1e-5, dtype: torch.dtype = F32, wino: bool = True) -> PackedConv:
     """Pack a PyTorch-layout weight for ``conv2d``.
 
     weight: Conv2d [K,Cin,R,S] | Linear [K,Cin] | (transposed2x2) ConvTranspose2d [Cin,Cout,2,2]
     bn:     optional (weight, bias, running_mean, running_var) folded into the epilogue:
-            FrozenBatchNorm2d [TV] / BatchNorm1d eval (ref models/match_head.py:62)."""
+            FrozenBatchNorm2d [TV] / BatchNorm1d eval (ref models/match_head.py:62).
+    wino:   also pack Winograd F(2x2,3x3) weights for fp32 stride-1 3x3 layers (the inference path); the grad-enabled
+            pass of the heads (autograd.py) packs per step and keeps the bit-exact fp32 fma chain of the implicit GEMM."""
     lib = _native.lib()
     weight = _req(weight.detach(), name="weight")
     if transposed2x2:
@@ -125,7 +127,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
         _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
                       "seam_pack_conv_weight_f32")
-        if mode == 0 and R == 3 and S == 3 and stride == 1:
+        if wino and mode == 0 and R == 3 and S == 3 and stride == 1:
             u = _pack_wino(lib, weight, K, cin, cs, 0)
     elif dtype == BX3:
         kred = lib.seam_conv_kred(cs, R, S)
@@ -155,7 +157,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
     return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u)
 
 
-def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0) -> PackedConv:
+def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -> PackedConv:
     """Weights of the INPUT-GRADIENT conv of a stride-1 Conv2d / Linear with OIHW weight [Cout,Cin,R,S]:
     dX = conv2d(dY, pack_conv_dgrad(W))  (taps rotated 180 degrees, channels swapped, pad R-1-pad_fwd)."""
     lib = _native.lib()
@@ -171,7 +173,7 @@ def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0) -> PackedConv:
     wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
     _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), cin, cout, R, S, cout, 2, _stream()),
                   "seam_pack_conv_weight_f32")
-    u = _pack_wino(lib, weight, cin, cout, cout, 2) if R == 3 else None
+    u = _pack_wino(lib, weight, cin, cout, cout, 2) if (wino and R == 3) else None
     return PackedConv(wp, None, None, cin, cout, R, S, 1, R - 1 - pad_fwd, cout, F32, u)
 
 
