@@ -33,6 +33,11 @@ namespace {
 
 constexpr unsigned kOob = 0x80000000u;
 
+#ifndef SEAM_WINO_ABL
+#define SEAM_WINO_ABL 0     // kernel experiments (operands keep the REAL data of chunks 0/1 -- zeros would run at a higher clock):
+                            // 1 no in-loop patch loads / LDS stores, 2 no in-loop weight loads, 4 no barrier, 8 no in-loop transforms
+#endif
+
 struct WinoArgs {
     const float* x;
     const float* u;       // packed transformed weights
@@ -200,6 +205,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
             for (int r = 0; r < 16; ++r) acc[nu][mt][r] = 0.f;
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
+#define A1(x) do { if (!(SEAM_WINO_ABL & 1)) { x; } } while (0)
+#define A8(x) do { if (!(SEAM_WINO_ABL & 8)) { x; } } while (0)
 #define MF(v, bf, mt, kk, nu) acc[nu][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][kk], bf[nu][kk], acc[nu][mt], 0, 0, 0)
 
     // ---- prologue -------------------------------------------------------------------------------------------------
@@ -214,11 +221,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
     load_raw(rset[1], 3);
     __syncthreads();
     transform(va, 0, 0);
+    if (SEAM_WINO_ABL & 8) transform(vb, 1, 0);
+    if (SEAM_WINO_ABL & 2) load_b(bf1, 1);
     if constexpr (MT == 1) __syncthreads();      // chunk 0 overwrites raw[0] right away
 
     // At the top of chunk t: raw[t&1] = patch(t), raw[(t+1)&1] = patch(t+1) (both visible), rset[t&1] = patch(t+2) in
     // flight, rset[(t+1)&1] = patch(t+3) in flight, bcur = weights(t), vcur = A fragments of (t, mt = 0).
     auto load_b2 = [&](f32x4 (&bf)[4], int chunk, int h) {      // half of load_b
+        if (SEAM_WINO_ABL & 2) return;
         const int c = chunk < last_chunk ? chunk : last_chunk;
 #pragma unroll
         for (int nu = 2 * h; nu < 2 * h + 2; ++nu)
@@ -227,35 +237,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
     auto chunk = [&](int t, int par, f32x4 (&bcur)[4], f32x4 (&bnext)[4], f32x4 (&vcur)[4], f32x4 (&vnext)[4]) {
         if constexpr (MT == 2) {
             // first half: MFMAs of (t, mt 0) from vcur; build vnext = fragments of (t, mt 1) from raw[par]
-            SB(); MF(vcur, bcur, 0, 0, 0); rd02(par, 1);
-            SB(); MF(vcur, bcur, 0, 0, 1);
-            SB(); MF(vcur, bcur, 0, 0, 2);
+            SB(); MF(vcur, bcur, 0, 0, 0); A8(rd02(par, 1));
+            SB(); MF(vcur, bcur, 0, 0, 1); load_b2(bnext, t + 1, 0);
+            SB(); MF(vcur, bcur, 0, 0, 2); load_b2(bnext, t + 1, 1);
             SB(); MF(vcur, bcur, 0, 0, 3);
-            SB(); MF(vcur, bcur, 0, 1, 0); c02(vnext);
-            SB(); MF(vcur, bcur, 0, 1, 1); rd13(par, 1);
+            SB(); MF(vcur, bcur, 0, 1, 0); A8(c02(vnext));
+            SB(); MF(vcur, bcur, 0, 1, 1); A8(rd13(par, 1));
             SB(); MF(vcur, bcur, 0, 1, 2);
             SB(); MF(vcur, bcur, 0, 1, 3);
-            SB(); MF(vcur, bcur, 0, 2, 0); c13a();
-            SB(); MF(vcur, bcur, 0, 2, 1); c13b(vnext);
-            SB(); MF(vcur, bcur, 0, 2, 2); load_b2(bnext, t + 1, 0);
-            SB(); MF(vcur, bcur, 0, 2, 3); load_b2(bnext, t + 1, 1);
+            SB(); MF(vcur, bcur, 0, 2, 0); A8(c13a());
+            SB(); MF(vcur, bcur, 0, 2, 1); A8(c13b(vnext));
+            SB(); MF(vcur, bcur, 0, 2, 2);
+            SB(); MF(vcur, bcur, 0, 2, 3);
             SB(); MF(vcur, bcur, 0, 3, 0);
             SB(); MF(vcur, bcur, 0, 3, 1);
             SB(); MF(vcur, bcur, 0, 3, 2);
             SB(); MF(vcur, bcur, 0, 3, 3);
             SB();
-            __syncthreads();                       // every wave is done reading raw[par]
+            if (!(SEAM_WINO_ABL & 4)) __syncthreads();                       // every wave is done reading raw[par]
             // second half: MFMAs of (t, mt 1) from vnext; patch(t+2) -> raw[par]; vcur = fragments of (t+1, mt 0)
-            SB(); MF(vnext, bcur, 1, 0, 0); store_raw(rset[par], par);
-            SB(); MF(vnext, bcur, 1, 0, 1); rd02(par ^ 1, 0);
-            SB(); MF(vnext, bcur, 1, 0, 2); load_raw(rset[par], t + 4);
+            SB(); MF(vnext, bcur, 1, 0, 0); A1(store_raw(rset[par], par));
+            SB(); MF(vnext, bcur, 1, 0, 1); A8(rd02(par ^ 1, 0));
+            SB(); MF(vnext, bcur, 1, 0, 2); A1(load_raw(rset[par], t + 4));
             SB(); MF(vnext, bcur, 1, 0, 3);
-            SB(); MF(vnext, bcur, 1, 1, 0); c02(vcur);
-            SB(); MF(vnext, bcur, 1, 1, 1); rd13(par ^ 1, 0);
+            SB(); MF(vnext, bcur, 1, 1, 0); A8(c02(vcur));
+            SB(); MF(vnext, bcur, 1, 1, 1); A8(rd13(par ^ 1, 0));
             SB(); MF(vnext, bcur, 1, 1, 2);
             SB(); MF(vnext, bcur, 1, 1, 3);
-            SB(); MF(vnext, bcur, 1, 2, 0); c13a();
-            SB(); MF(vnext, bcur, 1, 2, 1); c13b(vcur);
+            SB(); MF(vnext, bcur, 1, 2, 0); A8(c13a());
+            SB(); MF(vnext, bcur, 1, 2, 1); A8(c13b(vcur));
             SB(); MF(vnext, bcur, 1, 2, 2);
             SB(); MF(vnext, bcur, 1, 2, 3);
             SB(); MF(vnext, bcur, 1, 3, 0);
@@ -265,16 +275,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
             SB();
         } else {
             // one step per chunk: raw[par] (patch t) was consumed during chunk t-1; vnext = fragments of chunk t+1
-            SB(); MF(vcur, bcur, 0, 0, 0); store_raw(rset[par], par);
-            SB(); MF(vcur, bcur, 0, 0, 1); rd02(par ^ 1, 0);
-            SB(); MF(vcur, bcur, 0, 0, 2); load_raw(rset[par], t + 4);
+            SB(); MF(vcur, bcur, 0, 0, 0); A1(store_raw(rset[par], par));
+            SB(); MF(vcur, bcur, 0, 0, 1); A8(rd02(par ^ 1, 0));
+            SB(); MF(vcur, bcur, 0, 0, 2); A1(load_raw(rset[par], t + 4));
             SB(); MF(vcur, bcur, 0, 0, 3); load_b2(bnext, t + 1, 0);
-            SB(); MF(vcur, bcur, 0, 1, 0); c02(vnext);
-            SB(); MF(vcur, bcur, 0, 1, 1); rd13(par ^ 1, 0);
+            SB(); MF(vcur, bcur, 0, 1, 0); A8(c02(vnext));
+            SB(); MF(vcur, bcur, 0, 1, 1); A8(rd13(par ^ 1, 0));
             SB(); MF(vcur, bcur, 0, 1, 2); load_b2(bnext, t + 1, 1);
             SB(); MF(vcur, bcur, 0, 1, 3);
-            SB(); MF(vcur, bcur, 0, 2, 0); c13a();
-            SB(); MF(vcur, bcur, 0, 2, 1); c13b(vnext);
+            SB(); MF(vcur, bcur, 0, 2, 0); A8(c13a());
+            SB(); MF(vcur, bcur, 0, 2, 1); A8(c13b(vnext));
             SB(); MF(vcur, bcur, 0, 2, 2);
             SB(); MF(vcur, bcur, 0, 2, 3);
             SB(); MF(vcur, bcur, 0, 3, 0);
@@ -295,6 +305,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
         }
     }
 #undef SB
+#undef A1
+#undef A8
 #undef MF
 
     // ---- epilogue: output transform + scale/shift (+ residual, ReLU) ------------------------------------------------
