@@ -47,9 +47,22 @@ struct WinoArgs {
     float* y;
     int N, H, W, C, K;
     int Ho, Wo, pad, relu;
-    int TX, TY;           // tiles per block patch (TX*TY <= 32*MT)
-    int bx, by;           // blocks per image along x / y
-    int G;                // images per block (small maps: the whole tile grid of G images shares one block; bx = by = 1)
+    // Up to three regions tile an image: [0] the main region (exact multiple of its block patch), [1] the right strip,
+    // [2] the bottom strip -- each with its own patch shape, so edge blocks are not half empty.
+    int nreg;
+    int rx0[3], ry0[3];   // first tile column / row of the region
+    int rxe[3], rye[3];   // one past its last tile column / row
+    int TX[3], TY[3];     // tiles per block patch (TX*TY <= 32*MT)
+    int bx[3], by[3];     // blocks along x / y
+    int per_img;          // blocks per image (sum over regions)
+    // Stacked mode (small maps, e.g. the 14x14 ROI tiles of the heads): the tile rows of ALL images form one tall list
+    // (row R = n * tiles_y + ty); a block takes TY[0] consecutive rows at full width (TX[0] = tiles_x), crossing image
+    // boundaries.  Its raw patch lives in "padded row" space: image n owns rows [n * pitch, (n+1) * pitch), pitch =
+    // 2 * tiles_y + 2, padded row r of an image = its input row r - pad.
+    int stack;
+    int tiles_y;          // tile rows per image
+    int PH;               // stacked mode: raw patch rows (max over blocks)
+    int G;                // stacked mode: max images a block touches (else 1)
     int tiles_n;          // K / 32
     int nchunks;          // C / 8
 };
@@ -80,20 +93,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
     const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
     const int tm = tile / p.tiles_n;
     const int tn = tile - tm * p.tiles_n;
-    const int per_img = p.bx * p.by;
-    const int n_img = (tm / per_img) * p.G;                // first image of this block
-    const int rb = tm - (tm / per_img) * per_img;
+    const int per_img = p.per_img;
+    int rb = tm - (tm / per_img) * per_img;
+    int reg = 0;                                           // region of this block (wave-uniform scalar work)
+    if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
+        rb -= p.bx[0] * p.by[0];
+        reg = 1;
+        if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
+    }
+    const int TX = p.TX[reg], TY = p.TY[reg];
+    const int byi = rb / p.bx[reg];
+    const int bxi = rb - byi * p.bx[reg];
+    const int tys = p.tiles_y, pitch = 2 * tys + 2;
+    const int R0 = tm * TY;                                // stacked mode: first tile row (global) of this block
+    const int n_img = p.stack ? R0 / tys : tm / per_img;   // first image of this block
+    const int prow0 = p.stack ? 2 * (R0 - n_img * tys) : 0;    // stacked mode: padded row (of image n_img) the patch starts at
     const int n_here = min(p.G, p.N - n_img);              // images of this block that exist
-    const int byi = rb / p.bx;
-    const int bxi = rb - byi * p.bx;
-    const int ty0 = byi * p.TY, tx0 = bxi * p.TX;          // first tile of this block
-    const int iy0 = 2 * ty0 - p.pad, ix0 = 2 * tx0 - p.pad; // top-left input pixel of the raw patch
+    const int ty0 = p.stack ? 0 : p.ry0[reg] + byi * TY, tx0 = p.stack ? 0 : p.rx0[reg] + bxi * TX;   // first tile of this block
+    const int tye = p.rye[reg], txe = p.rxe[reg];          // the region's end (tiles beyond belong to other blocks)
+    const int iy0 = 2 * ty0 - p.pad, ix0 = 2 * tx0 - p.pad; // top-left input pixel of the raw patch (regions mode)
 
-    const int PW = 2 * p.TX + 2, PH = 2 * p.TY + 2;
-    const int NPIX1 = PW * PH;                             // patch pixels per image
-    const int NPIX = NPIX1 * p.G;
-    const int tpi = p.TX * p.TY;                           // tile slots per image
-    const int HS = p.TX + 1;                               // 16-byte entries per (patch row, x parity)
+    const int PW = 2 * TX + 2, PH = p.stack ? p.PH : 2 * TY + 2;
+    const int NPIX = PW * PH;
+    const int HS = TX + 1;                                 // 16-byte entries per (patch row, x parity)
+    const int nslots = TX * TY;
+    // tile slot -> (image offset g, tile row ty / column tx inside the image, first patch row, validity)
+    auto slot = [&](int id, int& g, int& ty, int& tx, int& prow) -> bool {
+        const int r = id / TX;
+        tx = tx0 + (id - r * TX);
+        if (p.stack) {
+            const int R = R0 + r;
+            const int n = R / tys;
+            g = n - n_img;
+            ty = R - n * tys;
+            prow = pitch * g + 2 * ty - prow0;
+            return id < nslots && n < p.N;
+        }
+        g = 0;
+        ty = ty0 + r;
+        prow = 2 * r;
+        return id < nslots && ty < tye && tx < txe;
+    };
 
     // ---- raw patch loader -----------------------------------------------------------------------------------------
     const size_t img_bytes = (size_t)p.H * p.W * p.C * 4;
@@ -107,14 +147,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
         const int half = idx & 1;
         const int pix = idx >> 1;
         const bool ok = pix < NPIX;
-        const int g = pix / NPIX1;
-        const int lp = pix - g * NPIX1;
-        const int py = lp / PW;
-        const int px = lp - py * PW;
-        const int gy = iy0 + py, gx = ix0 + px;
+        const int v = pix / PW;                            // patch row
+        const int px = pix - v * PW;
+        int g = 0, gy = iy0 + v;
+        if (p.stack) {
+            const int vr = prow0 + v;
+            g = vr / pitch;
+            gy = vr - g * pitch - p.pad;
+        }
+        const int gx = ix0 + px;
         const bool inb = ok && g < n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         goff[i] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + half * 4) * 4) : kOob;
-        loff[i] = ok ? (half * NPIX + g * NPIX1 + (py * 2 + (px & 1)) * HS + (px >> 1)) * 16 : 2 * NPIXMAX * 16;
+        loff[i] = ok ? (half * NPIX + (v * 2 + (px & 1)) * HS + (px >> 1)) * 16 : 2 * NPIXMAX * 16;
     }
     const int last_chunk = p.nchunks - 1;
     f32x4 rset[2][NI];
@@ -149,13 +193,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
     int rbase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        int id = mt * 32 + (lane & 31);
-        if (id >= tpi * p.G) id = 0;                       // idle tile slots read tile 0 (results are never stored)
-        const int g = id / tpi;
-        const int li = id - g * tpi;
-        const int tyl = li / p.TX;
-        const int txl = li - tyl * p.TX;
-        rbase[mt] = ((lane >> 5) * NPIX + g * NPIX1 + 4 * tyl * HS + txl) * 16;
+        int g, ty, tx, prow;
+        if (!slot(mt * 32 + (lane & 31), g, ty, tx, prow)) slot(0, g, ty, tx, prow);    // idle slots read tile 0 (never stored)
+        rbase[mt] = ((lane >> 5) * NPIX + prow * 2 * HS + (tx - tx0)) * 16;
     }
     const int oa = ra * row_bytes, ob = rbw * row_bytes;
     const int c1 = HS * 16;                                 // column offsets: j=0: 0, j=1: HS*16, j=2: 16, j=3: HS*16+16
@@ -332,13 +372,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
             ex[((xi * 2 + 1) * 32 + row) * 32 + (lane & 31)] = m1 - m2 - m3;
         }
         __syncthreads();
-        const int id = mt * 32 + et;
-        const int g = id / tpi;
-        const int li = id - g * tpi;
-        const bool tile_ok = g < n_here;
-        const int tyl = li / p.TX;
-        const int txl = li - tyl * p.TX;
-        const int oy = 2 * (ty0 + tyl), ox = 2 * (tx0 + txl);
+        int g, tyt, txt, prow_unused;
+        const bool tile_ok = slot(mt * 32 + et, g, tyt, txt, prow_unused) && g < n_here;
+        const int oy = 2 * tyt, ox = 2 * txt;
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
             const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
@@ -421,39 +457,97 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-// Patch shape for one tile variant: minimise the number of blocks (then the raw patch size) over TX*TY <= 32*MT; maps
-// whose whole tile grid fits several times into a block share it between G images (ROI tiles of the heads).
-struct Patch { int TX, TY, G, bx, by; long blocks; };   // blocks: per n-tile, for N images
+// Block layout for one tile variant (32*MT tile slots per block).  Small maps: the whole tile grid of G images per block.
+// Otherwise up to three regions per image: a main region tiled exactly by TX x TY patches, and the right / bottom strips
+// that remain, each tiled by the best patch for ITS shape -- a 100 x 100 tile map takes 157 blocks of 64 instead of 169.
+struct Layout {
+    int nreg, G, stack, PH;
+    int rx0[3], ry0[3], rxe[3], rye[3], TX[3], TY[3], bx[3], by[3];
+    long per_img, blocks;      // blocks: per n-tile, for N images
+};
 
-inline Patch choose_patch(int N, int tiles_x, int tiles_y, int mt, size_t in_img_bytes, size_t out_img_bytes) {
-    const int cap = 32 * mt, npixmax = mt == 2 ? 384 : 208;
-    Patch best;
-    best.blocks = -1;
-    const int whole = (2 * tiles_x + 2) * (2 * tiles_y + 2);
-    if (tiles_x * tiles_y <= cap && whole <= npixmax) {          // whole images per block
-        int g = cap / (tiles_x * tiles_y);
-        if (g * whole > npixmax) g = npixmax / whole;
-        while (g > 1 && ((size_t)g * in_img_bytes >= kOob || (size_t)g * out_img_bytes >= kOob)) --g;
-        if (g > N) g = N;
-        best.TX = tiles_x; best.TY = tiles_y; best.G = g; best.bx = best.by = 1;
-        best.blocks = (N + g - 1) / g;
-        return best;
-    }
-    long best_cost = -1;
-    for (int ty = 1; ty <= cap; ++ty)
-        for (int tx = 1; tx * ty <= cap; ++tx) {
-            const int npix = (2 * tx + 2) * (2 * ty + 2);
-            if (npix > npixmax) continue;
-            const long nb = (long)((tiles_x + tx - 1) / tx) * ((tiles_y + ty - 1) / ty);
-            const long cost = nb * 4096 + npix;
-            if (best_cost < 0 || cost < best_cost) {
-                best_cost = cost;
-                best.TX = tx; best.TY = ty; best.G = 1;
-                best.bx = (tiles_x + tx - 1) / tx; best.by = (tiles_y + ty - 1) / ty;
-                best.blocks = nb * N;
-            }
+inline bool patch_ok(int tx, int ty, int cap, int npixmax) { return tx >= 1 && ty >= 1 && tx * ty <= cap && (2 * tx + 2) * (2 * ty + 2) <= npixmax; }
+
+// best uniform tiling of a w x h tile rectangle: fewest blocks, then the smallest raw patch
+inline long best_uniform(int w, int h, int cap, int npixmax, int& TX, int& TY) {
+    long best = -1, best_cost = -1;
+    for (int ty = 1; ty <= cap && ty <= h; ++ty)
+        for (int tx = 1; tx * ty <= cap && tx <= w; ++tx) {
+            if (!patch_ok(tx, ty, cap, npixmax)) continue;
+            const long nb = (long)((w + tx - 1) / tx) * ((h + ty - 1) / ty);
+            const long cost = nb * 4096 + (2 * tx + 2) * (2 * ty + 2);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; TX = tx; TY = ty; }
         }
     return best;
+}
+
+inline Layout choose_layout(int N, int tiles_x, int tiles_y, int mt, size_t in_img_bytes, size_t out_img_bytes) {
+    const int cap = 32 * mt, npixmax = mt == 2 ? 384 : 208;
+    Layout L;
+    L.nreg = 1; L.G = 1; L.stack = 0; L.PH = 0;
+    // Stacked candidate (maps narrower than a block): TY consecutive tile rows of the batch at full width per block.
+    Layout S;
+    S.blocks = -1;
+    if (tiles_x <= cap) {
+        const int t = tiles_y, pitch = 2 * t + 2, pw = 2 * tiles_x + 2;
+        for (int ty = cap / tiles_x; ty >= 1; --ty) {
+            int phmax = 0, gmax = 0;
+            for (int b = 0; b < t; ++b) {                                // block starts repeat with period <= tiles_y
+                const int tyf = (int)(((long)b * ty) % t);
+                const int last = tyf + ty - 1;
+                const int gl = last / t, tyl = last - gl * t;
+                const int span = pitch * gl + 2 * tyl + 4 - 2 * tyf;
+                if (span > phmax) phmax = span;
+                if (gl + 1 > gmax) gmax = gl + 1;
+            }
+            if (phmax * pw > npixmax) continue;
+            if ((size_t)gmax * in_img_bytes >= kOob || (size_t)gmax * out_img_bytes >= kOob) continue;
+            S.nreg = 1; S.stack = 1; S.PH = phmax; S.G = gmax;
+            S.rx0[0] = S.ry0[0] = 0; S.rxe[0] = tiles_x; S.rye[0] = tiles_y; S.TX[0] = tiles_x; S.TY[0] = ty; S.bx[0] = S.by[0] = 1;
+            S.per_img = 1;
+            S.blocks = ((long)N * t + ty - 1) / ty;
+            break;
+        }
+    }
+    // one region (uniform tiling) is the baseline
+    long best_blocks = best_uniform(tiles_x, tiles_y, cap, npixmax, L.TX[0], L.TY[0]);
+    L.rx0[0] = L.ry0[0] = 0; L.rxe[0] = tiles_x; L.rye[0] = tiles_y;
+    L.bx[0] = (tiles_x + L.TX[0] - 1) / L.TX[0]; L.by[0] = (tiles_y + L.TY[0] - 1) / L.TY[0];
+    // main region + strips
+    for (int ty = 1; ty <= cap && ty <= tiles_y; ++ty)
+        for (int tx = 1; tx * ty <= cap && tx <= tiles_x; ++tx) {
+            if (!patch_ok(tx, ty, cap, npixmax)) continue;
+            const int mx = tiles_x / tx, my = tiles_y / ty;              // exact blocks of the main region
+            const int wm = mx * tx, hm = my * ty;
+            if (wm == 0 || hm == 0) continue;
+            Layout C;
+            C.G = 1; C.nreg = 1; C.stack = 0; C.PH = 0;
+            C.rx0[0] = 0; C.ry0[0] = 0; C.rxe[0] = wm; C.rye[0] = hm; C.TX[0] = tx; C.TY[0] = ty; C.bx[0] = mx; C.by[0] = my;
+            long nb = (long)mx * my;
+            if (wm < tiles_x) {                                          // right strip: full height
+                const int r = C.nreg++;
+                const long b = best_uniform(tiles_x - wm, tiles_y, cap, npixmax, C.TX[r], C.TY[r]);
+                C.rx0[r] = wm; C.ry0[r] = 0; C.rxe[r] = tiles_x; C.rye[r] = tiles_y;
+                C.bx[r] = (tiles_x - wm + C.TX[r] - 1) / C.TX[r]; C.by[r] = (tiles_y + C.TY[r] - 1) / C.TY[r];
+                nb += b;
+            }
+            if (hm < tiles_y) {                                          // bottom strip: under the main region only
+                const int r = C.nreg++;
+                const long b = best_uniform(wm, tiles_y - hm, cap, npixmax, C.TX[r], C.TY[r]);
+                C.rx0[r] = 0; C.ry0[r] = hm; C.rxe[r] = wm; C.rye[r] = tiles_y;
+                C.bx[r] = (wm + C.TX[r] - 1) / C.TX[r]; C.by[r] = (tiles_y - hm + C.TY[r] - 1) / C.TY[r];
+                nb += b;
+            }
+            if (nb < best_blocks) {
+                best_blocks = nb;
+                L = C;
+            }
+        }
+    L.per_img = 0;
+    for (int r = 0; r < L.nreg; ++r) L.per_img += (long)L.bx[r] * L.by[r];
+    L.blocks = L.per_img * N;
+    if (S.blocks > 0 && S.blocks < L.blocks) return S;
+    return L;
 }
 
 inline bool wino_ok(int C, int K, int R, int S, int stride) { return R == 3 && S == 3 && stride == 1 && C % 8 == 0 && K % 32 == 0 && C >= 8; }
@@ -485,15 +579,21 @@ static int wino_plan(WinoArgs& a, int N, int H, int W, int C, int K, int pad, in
     const int tiles_x = (a.Wo + 1) / 2, tiles_y = (a.Ho + 1) / 2;
     static const int force_mt = getenv("SEAM_WINO_MT") ? atoi(getenv("SEAM_WINO_MT")) : 0;    // kernel experiments
     const size_t in_b = (size_t)H * W * C * 4, out_b = (size_t)a.Ho * a.Wo * K * 4;
-    const Patch p2 = choose_patch(N, tiles_x, tiles_y, 2, in_b, out_b), p1 = choose_patch(N, tiles_x, tiles_y, 1, in_b, out_b);
+    const Layout p2 = choose_layout(N, tiles_x, tiles_y, 2, in_b, out_b), p1 = choose_layout(N, tiles_x, tiles_y, 1, in_b, out_b);
     a.tiles_n = K / 32;
     a.nchunks = C / 8;
     // Tile variant: a 64-tile block costs ~1.9x a 32-tile block (same weight stream, twice the MFMAs); take the 32-tile
     // variant when it wastes fewer slots, or when the 64-tile grid could not fill the chip twice.
     mt = (p1.blocks * 100 < p2.blocks * 190 || p2.blocks * a.tiles_n < 1024) ? 1 : 2;
     if (force_mt == 1 || force_mt == 2) mt = force_mt;
-    const Patch& pp = mt == 2 ? p2 : p1;
-    a.TX = pp.TX; a.TY = pp.TY; a.G = pp.G; a.bx = pp.bx; a.by = pp.by;
+    const Layout& pp = mt == 2 ? p2 : p1;
+    a.nreg = pp.nreg; a.G = pp.G; a.per_img = (int)pp.per_img;
+    a.stack = pp.stack; a.PH = pp.PH; a.tiles_y = tiles_y;
+    for (int r = 0; r < 3; ++r) {
+        const int q = r < pp.nreg ? r : 0;
+        a.rx0[r] = pp.rx0[q]; a.ry0[r] = pp.ry0[q]; a.rxe[r] = pp.rxe[q]; a.rye[r] = pp.rye[q];
+        a.TX[r] = pp.TX[q]; a.TY[r] = pp.TY[q]; a.bx[r] = pp.bx[q]; a.by[r] = pp.by[q];
+    }
     blocks = pp.blocks * a.tiles_n;
     if (blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
     return 0;

@@ -44,6 +44,9 @@ WINO_CASES = [
     (7, 256, 10, 10, 256, 0, False, False, True),     # 4x4 tiles per image: several images share a block, last block ragged
     (11, 256, 8, 8, 64, 0, False, True, True),        # 3x3 tiles per image, 6 (or 3) images per block, residual
     (5, 64, 12, 12, 64, 0, False, False, False),      # 5x5 tiles per image, 2 images per block, odd image count
+    (1, 32, 200, 200, 32, 1, False, False, True),     # 100x100 tiles: main region + right strip + bottom strip
+    (2, 16, 100, 50, 32, 1, False, True, False),      # 25 x 50 tiles: strips with their own patch shapes, residual
+    (1, 8, 51, 35, 32, 0, False, False, False),       # odd valid map: 17 x 25 tiles (half tiles on both edges)
 ]
 
 
