@@ -29,9 +29,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 namespace {
 
 constexpr unsigned kOob = 0x80000000u;
+
+// Packed-fp32 VALU ops for the input transform.  Written as asm because the DAG combiner scalarises a <4 x float> op
+// whose lanes are extracted one by one (each feeds its own MFMA): 32 v_fma/v_sub per transform instead of 16 packed ones.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x4 fma4(f32x2 c, f32x4 b, f32x4 a) {        // a + c * b
+    const f32x2 lo = pk_fma(c, __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(a, a, 0, 1));
+    const f32x2 hi = pk_fma(c, __builtin_shufflevector(b, b, 2, 3), __builtin_shufflevector(a, a, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_add(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_add(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_sub(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_sub(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 
 #ifndef SEAM_WINO_ABL
 #define SEAM_WINO_ABL 0     // kernel experiments (operands keep the REAL data of chunks 0/1 -- zeros would run at a higher clock):
@@ -218,19 +253,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
         xa3 = *reinterpret_cast<const f32x4*>(base + oa + c1 + 16);
         xb3 = *reinterpret_cast<const f32x4*>(base + ob + c1 + 16);
     };
+    const f32x2 cb2 = {cb, cb};
     auto c02 = [&](f32x4 (&v)[4]) {
-        const f32x4 t0 = xa0 + cb * xb0;
-        t2 = xa2 + cb * xb2;
-        v[0] = t0 - t2;
+        const f32x4 t0 = fma4(cb2, xb0, xa0);
+        t2 = fma4(cb2, xb2, xa2);
+        v[0] = sub4(t0, t2);
     };
     auto c13a = [&]() {
-        t1 = xa1 + cb * xb1;
-        t3 = xa3 + cb * xb3;
+        t1 = fma4(cb2, xb1, xa1);
+        t3 = fma4(cb2, xb3, xa3);
     };
     auto c13b = [&](f32x4 (&v)[4]) {
-        v[1] = t1 + t2;
-        v[2] = t2 - t1;
-        v[3] = t1 - t3;
+        v[1] = add4(t1, t2);
+        v[2] = sub4(t2, t1);
+        v[3] = sub4(t1, t3);
     };
     auto transform = [&](f32x4 (&v)[4], int buf, int mt) {
         rd02(buf, mt); rd13(buf, mt); c02(v); c13a(); c13b(v);
