@@ -34,6 +34,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -80,75 +81,80 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
     const int wm0 = (wid >> 1) * WM;
     const int wn0 = (wid & 1) * WN;
 
-    // ---- XCD-aware tile id (bijective for any grid size) --------------------------------------
-    const int nblk = gridDim.x;
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int q8 = nblk >> 3, rem = nblk & 7;
-    const int tile = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (b >> 3);
-    const int tm = tile / p.tiles_n;
-    const int tn = tile - tm * p.tiles_n;
-    const int m0 = tm * BM;
-    const int n0 = tn * BN;
-
-    // ---- loader state -------------------------------------------------------------------------
-    // The A descriptor is rebased at the first image of this tile so lane offsets stay < 2 GiB for
-    // any batch size (a 128-row tile never spans 2 GiB of input).
+    // ---- persistent tiles --------------------------------------------------------------------
+    // A block walks tiles vb = blockIdx.x, + gridDim.x, ... (grid = the resident block slots, a multiple of 8, so a block
+    // stays on its XCD); vb -> tile is the XCD-aware bijection over all tiles (consecutive tiles stay on one XCD's L2).
+    // The first D chunks of the NEXT tile are issued before the epilogue of the current one: the load latency that a
+    // fresh block would sit through hides behind the epilogue's stores, which matters for the short reductions
+    // (1x1 layers with C = 64 / 128: 2-4 chunks per tile).
+    const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = p.kred / BKE;
     const int lcol = tid & 7;     // which 16-byte vector of the chunk
     const int lrow = tid >> 3;    // 0..RP-1
     const int HoWo = p.Ho * p.Wo;
-    const int n_first = m0 / HoWo;
     const size_t img_elems = (size_t)p.H * p.W * p.C;
-    const size_t rem_bytes = ((size_t)(p.N - n_first) * img_elems) * ES;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.x + (size_t)n_first * img_elems * ES), 0,
-        (int)(rem_bytes > kOob ? kOob : (unsigned)rem_bytes), 0x00020000);
-    // weight slabs are [n_slab][chunk][slab_bn][128 B]; a BN < slab_bn tile reads its rows inside each slab
     const int slab_stride = p.slab_bn * CHUNK_BYTES;
-    const int n_in_slab = n0 % p.slab_bn;
-    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.w + (size_t)(n0 - n_in_slab) * p.kred * ES + (size_t)n_in_slab * CHUNK_BYTES), 0,
-        (int)((unsigned)nk * (unsigned)slab_stride), 0x00020000);
 
+    // per-tile loader state (rewritten by setup())
+    int m0, n0;
+    __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
     int arow[AI], ahi[AI], awi[AI];      // byte offset of the (r=0,s=0,c=0) tap; top-left input coordinate
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int m = m0 + lrow + RP * i;
-        if (m < p.M) {
-            const int n = m / HoWo;
-            const int rm = m - n * HoWo;
-            const int ho = rm / p.Wo;
-            const int wo = rm - ho * p.Wo;
-            ahi[i] = ho * p.stride - p.pad;
-            awi[i] = wo * p.stride - p.pad;
-            arow[i] = ((((n - n_first) * p.H + ahi[i]) * p.W + awi[i]) * p.C) * ES;
-        } else {
-            ahi[i] = -(1 << 28);
-            awi[i] = 0;
-            arow[i] = 0;
-        }
-    }
-    int brow[BI];
-#pragma unroll
-    for (int i = 0; i < BI; ++i) brow[i] = (lrow + RP * i) * CHUNK_BYTES + lcol * 16;     // inside a [BN][128 B] slab
-
-    // (r, s, c) of this thread's 16-byte vector inside the chunk being fetched, and its byte offset.
-    // C >= one chunk: chunks are walked (r, c-chunk, s) -- exactly the order of the packed slabs.
     int kc, kr, ks, tapoff;
-    {
+    // Number of the chunk being fetched.  Derived from kernel arguments only, so the weight-slab
+    // offset below is provably wave-uniform (an SGPR soffset; a lane-tainted value would put every
+    // buffer load into a waterfall loop).  Chunks >= nk are fetched too, but out of range: the
+    // loads stay UNCONDITIONAL, the hardware returns zeros and nobody reads them.
+    int uq;
+    auto setup = [&](int vb) {
+        const int xcd = vb & 7;
+        const int q8 = ntiles >> 3, rem = ntiles & 7;
+        const int tile = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (vb >> 3);
+        const int tm = tile / p.tiles_n;
+        const int tn = tile - tm * p.tiles_n;
+        m0 = tm * BM;
+        n0 = tn * BN;
+        // The A descriptor is rebased at the first image of this tile so lane offsets stay < 2 GiB for
+        // any batch size (a 128-row tile never spans 2 GiB of input).
+        const int n_first = m0 / HoWo;
+        const size_t rem_bytes = ((size_t)(p.N - n_first) * img_elems) * ES;
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)p.x + (size_t)n_first * img_elems * ES), 0,
+            (int)(rem_bytes > kOob ? kOob : (unsigned)rem_bytes), 0x00020000);
+        // weight slabs are [n_slab][chunk][slab_bn][128 B]; a BN < slab_bn tile reads its rows inside each slab
+        const int n_in_slab = n0 % p.slab_bn;
+        b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)p.w + (size_t)(n0 - n_in_slab) * p.kred * ES + (size_t)n_in_slab * CHUNK_BYTES), 0,
+            (int)((unsigned)nk * (unsigned)slab_stride), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int m = m0 + lrow + RP * i;
+            if (m < p.M) {
+                const int n = m / HoWo;
+                const int rm = m - n * HoWo;
+                const int ho = rm / p.Wo;
+                const int wo = rm - ho * p.Wo;
+                ahi[i] = ho * p.stride - p.pad;
+                awi[i] = wo * p.stride - p.pad;
+                arow[i] = ((((n - n_first) * p.H + ahi[i]) * p.W + awi[i]) * p.C) * ES;
+            } else {
+                ahi[i] = -(1 << 28);
+                awi[i] = 0;
+                arow[i] = 0;
+            }
+        }
+        // (r, s, c) of this thread's 16-byte vector inside the chunk being fetched, and its byte offset.
+        // C >= one chunk: chunks are walked (r, c-chunk, s) -- exactly the order of the packed slabs.
         const int kk = lcol * EPV;
         const int pos = kk / p.C;          // C >= BKE: pos = 0
         kc = kk - pos * p.C;
         kr = pos / p.S;
         ks = pos - kr * p.S;
         tapoff = ((kr * p.W + ks) * p.C + kc) * ES;
-    }
-    // Number of the chunk being fetched.  Derived from kernel arguments only, so the weight-slab
-    // offset below is provably wave-uniform (an SGPR soffset; a lane-tainted value would put every
-    // buffer load into a waterfall loop).  Chunks >= nk are fetched too, but out of range: the
-    // loads stay UNCONDITIONAL, the hardware returns zeros and nobody reads them.
-    int uq = 0;
+        uq = 0;
+    };
+    int brow[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) brow[i] = (lrow + RP * i) * CHUNK_BYTES + lcol * 16;     // inside a [BN][128 B] slab
 
     // A ring of D register sets: the loads issued during chunk t are for chunk t+D, and are written to LDS
     // during chunk t+D-1 -- D-1 chunks of MFMAs of slack.  fp32 chunks are long (64 MFMAs x 64 cycles per
@@ -195,12 +201,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
     };
 
     f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int aoff = (wm0 + (lane & 31)) * LDB + (lane >> 5) * 16;
     const int boff = (wn0 + (lane & 31)) * LDB + (lane >> 5) * 16;
@@ -264,11 +264,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
         for (int q = 0; q < Q; ++q) mf(fa1, fb1, q);
     };
 
-    load_chunk(areg[0], breg[0]);                   // chunk 0 -> LDS buffer 0
+    setup(blockIdx.x);
 #pragma unroll
-    for (int r = 0; r < AI + BI; ++r) store_row(areg[0], breg[0], 0, r);
+    for (int d = 0; d < D; ++d) load_chunk(areg[d], breg[d]);      // chunks 0..D-1 of the first tile
+
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
 #pragma unroll
-    for (int d = 1; d < D; ++d) load_chunk(areg[d], breg[d]);      // chunks 1..D-1 wait in registers
+    for (int r = 0; r < AI + BI; ++r) store_row(areg[0], breg[0], 0, r);       // chunk 0 -> LDS buffer 0; 1..D-1 wait in registers
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     __syncthreads();
     read_frags(fa0, fb0, 0, 0);
 
@@ -279,22 +287,99 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
         for (int u = 0; u < P; ++u)
             if (t + u < nk) chunk(u & 1, areg[u % D], breg[u % D], areg[(u + 1) % D], breg[(u + 1) % D]);
     }
+    __syncthreads();                 // every wave is done with both LDS buffers: the next tile's chunk 0 may land
+
+    // ---- next tile: addressing + its first D chunks in flight before this tile's epilogue ------
+    // (fp16 runs D = 3 register sets: holding them across the epilogue would spill, so it fetches after the epilogue)
+    constexpr bool PREFETCH = false;    // measured: no gain on any layer shape (A/B on one box), and the D register sets held across the epilogue spill
+    const int cm0 = m0, cn0 = n0;
+    auto next_tile = [&]() {
+        const int nvb = vb + (int)gridDim.x;
+        setup(nvb < ntiles ? nvb : vb);          // last tile of this block: re-fetch the current one (never used)
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_chunk(areg[d], breg[d]);
+    };
+    if constexpr (PREFETCH) next_tile();
 
     // ---- epilogue: y = act(acc*scale + shift + residual) --------------------------------------
     // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Branch-free: residual loads / stores are raw buffer ops rebased at this tile's first row;
     // rows >= M or cols >= K get an out-of-range offset (loads return 0, stores are dropped), so all
     // residual loads of a wave are in flight together instead of one vmcnt(0) per element.
+    // (the lane id goes through an opaque asm so that the per-lane offsets below are recomputed per tile instead of being
+    //  hoisted out of the persistent loop, where 64 of them would stay live across the K loop)
+    int lq = lane;
+    asm volatile("" : "+v"(lq));
     const int YS = (F16 && !p.y_f32) ? 2 : 4;       // output element size
-    const size_t tile_off = (size_t)m0 * p.K;
-    const unsigned rows_here = (unsigned)min(BM, p.M - m0);
+    const size_t tile_off = (size_t)cm0 * p.K;
+    const unsigned rows_here = (unsigned)min(BM, p.M - cm0);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((char*)p.y + tile_off * YS), 0, (int)(rows_here * (unsigned)p.K * YS), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)(p.res ? p.res : p.y) + tile_off * ES), 0, (int)(rows_here * (unsigned)p.K * ES), 0x00020000);
+    bool vec_done = false;
+    if constexpr (!F16) {
+        // K % 4 == 0 (every layer but the 15- / 14-wide logit heads): the accumulators go through a wave-private LDS
+        // transpose so that a lane owns 4 consecutive output channels: 16-byte residual loads and stores, 4x fewer
+        // vector-memory instructions than the element-wise form (the short reductions -- 1x1 layers with C = 64 / 128 --
+        // spend as long in the texture path on 64 scalar stores per wave as in their MFMAs) and 256-byte row segments.
+        if ((p.K & 3) == 0) {
+            vec_done = true;
+            constexpr int EW = WN + 4;                 // padded row, floats
+            constexpr int LPR = WN / 4;                // lanes per row
+            constexpr int RPI = 64 / LPR;              // rows per 16-byte pass of the wave
+            constexpr int NP = 32 / RPI;               // passes per 32-row MFMA tile
+            float* eb = reinterpret_cast<float*>(BM >= BN ? &As[0][0] : &Bs[0][0]) + wid * 32 * EW;
+            const int er = lq / LPR, ec = (lq % LPR) * 4;
+            const int n = cn0 + wn0 + ec;
+            const bool nok = n < p.K;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale && nok) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift && nok) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        eb[((r & 3) + 8 * (r >> 2) + 4 * (lq >> 5)) * EW + j * 32 + (lq & 31)] = acc[i][j][r];
+                unsigned eo[NP];
+                f32x4 rv[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int row = wm0 + i * 32 + k * RPI + er;
+                    eo[k] = nok ? (unsigned)(row * p.K + n) * 4u : kOob;
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, eo[k], 0, 0));
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&eb[(k * RPI + er) * EW + ec]) * sc + sh;
+                    if (p.res) {
+                        if (p.relu == 2) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = rv[k][e] > 0.f ? v[e] : 0.f;    // ReLU mask of `res` (backward)
+                        } else {
+                            v += rv[k];
+                        }
+                    }
+                    if (p.relu == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, eo[k], 0, 0);
+                }
+            }
+            __syncthreads();          // the transpose regions overlap the LDS buffers the next tile's chunk 0 goes to
+        }
+    }
+    if (!vec_done)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn0 + j * 32 + (lane & 31);
+        const int n = cn0 + wn0 + j * 32 + (lq & 31);
         const bool nok = n < p.K;
         const float sc = (p.scale && nok) ? p.scale[n] : 1.f;
         const float sh = (p.shift && nok) ? p.shift[n] : 0.f;
@@ -304,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
             float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lq >> 5);
                 eo[r] = (unsigned)(row * p.K + n);
             }
             if (p.res) {
@@ -337,6 +422,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
             }
         }
     }
+    if constexpr (!PREFETCH) next_tile();
+    }   // persistent tile loop
 }
 
 // =====================================================================================================================
@@ -765,7 +852,12 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     choose_tile(sizeof(T) == 2 ? P_F16 : P_F32, a.M, K, best_bm, best_bn);
     a.tiles_m = (a.M + best_bm - 1) / best_bm;
     a.tiles_n = rows / best_bn;
-    const dim3 grid(a.tiles_m * a.tiles_n);
+    // persistent blocks: one per resident slot (256 CUs x 2 blocks of 4 waves, or x 1 block of 8 waves); a multiple of 8 so
+    // that a block's tiles stay on its XCD
+    static const int slots4 = getenv("SEAM_CONV_SLOTS") ? atoi(getenv("SEAM_CONV_SLOTS")) : 512;      // dev knob
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int slots = best_bm == 256 ? slots4 / 2 : slots4;
+    const dim3 grid(ntiles < slots ? ntiles : slots);
     static const int dyn = getenv("SEAM_CONV_DYNLDS") ? atoi(getenv("SEAM_CONV_DYNLDS")) : 0;   // dev knob: occupancy experiments
     hipStream_t st = (hipStream_t)stream;
     if (best_bm == 256) hipLaunchKernelGGL((conv_igemm<T, 256, 128, 8>), grid, dim3(512), dyn, st, a);
