@@ -77,6 +77,15 @@ int seam_conv2d_f32(const float* x, const float* w_packed, const float* scale,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     int relu, seam_stream_t stream);
 
+/* The same convolution with the FPN top-down merge [TV FeaturePyramidNetwork.forward: inner_lateral +
+ * F.interpolate(last_inner, size=feat_shape, mode="nearest")] fused into its epilogue (SURVEY 8b
+ * `seam_fpn_topdown_add_f32`): y = act(conv(x)*scale + shift + top[n, floor(ho*Ht/Ho), floor(wo*Wt/Wo), :]),
+ * top NHWC [N,Ht,Wt,K], K % 4 == 0.  Same rounding order as seam_conv2d_f32 followed by seam_upsample_add_f32
+ * (bit-identical), without writing and re-reading the lateral map. */
+int seam_conv2d_upres_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                          const float* top, float* y, int N, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, int Ht, int Wt, int relu, seam_stream_t stream);
+
 /* fp16 variant (BASELINE config 5: "fp16 MFMA path with fp32 ... accumulation"): x, w_packed,
  * residual are IEEE fp16 (NHWC, C multiple of 8 and, when C >= 64, of 64); v_mfma_f32_32x32x16_f16
  * with fp32 accumulators; scale/shift stay fp32; y is fp16, or fp32 when y_f32 != 0 (the last trunk
@@ -100,6 +109,14 @@ int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int ou
 
 int seam_preprocess_f16(const float* img, void* out /* fp16 NHWC8 */, int in_h, int in_w, int out_h,
                         int out_w, int Hp, int Wp, seam_stream_t stream);
+
+/* The same transform for n images of ONE shape laid out at a constant stride (img_stride floats between
+ * consecutive images: the frames of a clip tensor [T,3,H,W], which the reference hands over as a list of views):
+ * one launch writes the whole NHWC batch [n,Hp,Wp,4] (fp16: [n,Hp,Wp,8]).  n <= 65535. */
+int seam_preprocess_batch_f32(const float* imgs, size_t img_stride, float* out, int n, int in_h, int in_w,
+                              int out_h, int out_w, int Hp, int Wp, seam_stream_t stream);
+int seam_preprocess_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w,
+                              int out_h, int out_w, int Hp, int Wp, seam_stream_t stream);
 
 /* Same transform fed by a uint8 HWC RGB frame [in_h,in_w,3]: fuses ToTensor (x/255, stuffs/transform.py:46-49)
  * so a clip crosses PCIe at 1 byte per sample (device side).  out: fp32 NHWC4 or, when

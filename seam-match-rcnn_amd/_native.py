@@ -32,6 +32,7 @@ SIGNATURES = {
     "seam_conv_tile_prec": (_i, [_i, _i, _i]),
     "seam_pack_conv_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv2d_upres_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_pack_conv_weight_bx3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_bx3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_wino_supported": (_i, [_i, _i, _i, _i, _i]),
@@ -44,6 +45,8 @@ SIGNATURES = {
     "seam_pack_conv_weight_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_preprocess_batch_f32": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_preprocess_batch_f16": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_maxpool2d_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

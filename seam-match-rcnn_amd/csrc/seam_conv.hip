@@ -58,6 +58,8 @@ struct ConvArgs {
     int y_f32;         // fp16 kernel only: write fp32 output (descriptor heads stay fp32)
     int slab_bn;       // rows per packed weight slab (128 or 64; fixed at pack time, >= the tile's BN)
     int tiles_m, tiles_n;
+    int rH, rW;        // > 0 (fp32, K % 4 == 0 only): `res` is a coarser map [N, rH, rW, K] added through a nearest-neighbour
+                       // upsample to [Ho, Wo] (ATen: src = min(floor(dst * rH / Ho), rH - 1)) -- the FPN top-down merge
 };
 
 template <typename T, int BM, int BN, int NW>
@@ -317,6 +319,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
         (void*)((char*)p.y + tile_off * YS), 0, (int)(rows_here * (unsigned)p.K * YS), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)(p.res ? p.res : p.y) + tile_off * ES), 0, (int)(rows_here * (unsigned)p.K * ES), 0x00020000);
+    // coarse residual map (rH > 0), rebased at the first image of this tile (a tile spans at most a few images)
+    const int up_first = cm0 / HoWo;
+    const size_t up_img = (size_t)p.rH * p.rW * p.K * 4;
+    const size_t up_rem = (size_t)(p.N - up_first) * up_img;
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(p.res ? p.res : p.y) + (p.rH > 0 ? (size_t)up_first * up_img : 0)), 0,
+        (int)(up_rem > kOob ? kOob : (unsigned)up_rem), 0x00020000);
     bool vec_done = false;
     if constexpr (!F16) {
         // K % 4 == 0 (every layer but the 15- / 14-wide logit heads): the accumulators go through a wave-private LDS
@@ -350,7 +359,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
                     const int row = wm0 + i * 32 + k * RPI + er;
                     eo[k] = nok ? (unsigned)(row * p.K + n) * 4u : kOob;
                 }
-                if (p.res) {
+                if (p.res && p.rH > 0) {
+                    // nearest-upsampled residual: output pixel (img, ho, wo) reads the coarse pixel (img, ht, wt)
+                    const float shs = (float)p.rH / (float)p.Ho, sws = (float)p.rW / (float)p.Wo;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int m = cm0 + wm0 + i * 32 + k * RPI + er;
+                        const int img = m / HoWo;
+                        const int rm = m - img * HoWo;
+                        const int ho = rm / p.Wo;
+                        const int wo = rm - ho * p.Wo;
+                        const int ht = min((int)floorf((float)ho * shs), p.rH - 1);
+                        const int wt = min((int)floorf((float)wo * sws), p.rW - 1);
+                        const unsigned uo = (nok && m < p.M) ? (unsigned)((((img - up_first) * p.rH + ht) * p.rW + wt) * p.K + n) * 4u : kOob;
+                        rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uo, 0, 0));
+                    }
+                } else if (p.res) {
 #pragma unroll
                     for (int k = 0; k < NP; ++k)
                         rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, eo[k], 0, 0));
@@ -832,7 +856,8 @@ inline void choose_tile(int prec, int M, int K, int& best_bm, int& best_bn) {
 
 template <typename T>
 int conv2d(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
-           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, int y_f32, void* stream) {
+           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, int y_f32, void* stream,
+           int rH = 0, int rW = 0) {
     constexpr int BKE = CHUNK_BYTES / (int)sizeof(T), EPV = 16 / (int)sizeof(T);
     if ((C % EPV) || (C >= BKE && C % BKE) || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     ConvArgs a;
@@ -845,7 +870,9 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.M = N * a.Ho * a.Wo;
     a.relu = relu;
     a.y_f32 = y_f32;
+    a.rH = rH; a.rW = rW;
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
+    if (rH > 0 && (sizeof(T) != 4 || (K & 3) || rW <= 0 || !residual || relu == 2)) return (int)hipErrorInvalidValue;
     const int rows = ((K + 63) / 64) * 64;
     a.slab_bn = rows % 128 == 0 ? 128 : 64;
     int best_bm, best_bn;
@@ -881,6 +908,7 @@ int conv2d_bx3(const void* x, const void* w_packed, const float* scale, const fl
     a.M = N * a.Ho * a.Wo;
     a.relu = relu;
     a.y_f32 = 1;
+    a.rH = 0; a.rW = 0;
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
     const int rows = ((K + 63) / 64) * 64;
     a.slab_bn = rows % 128 == 0 ? 128 : 64;
@@ -930,6 +958,13 @@ int seam_conv2d_f32(const float* x, const float* w_packed, const float* scale, c
                     const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S, int stride,
                     int pad, int relu, void* stream) {
     return conv2d<float>(x, w_packed, scale, shift, residual, y, N, H, W, C, K, R, S, stride, pad, relu, 1, stream);
+}
+
+int seam_conv2d_upres_f32(const float* x, const float* w_packed, const float* scale, const float* shift, const float* top,
+                          float* y, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ht, int Wt,
+                          int relu, void* stream) {
+    if (Ht <= 0 || Wt <= 0) return (int)hipErrorInvalidValue;
+    return conv2d<float>(x, w_packed, scale, shift, top, y, N, H, W, C, K, R, S, stride, pad, relu, 1, stream, Ht, Wt);
 }
 
 int seam_conv2d_f16(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual,

@@ -30,11 +30,13 @@ __device__ __forceinline__ void bilinear_axis(int dst, int in, int out, int& i0,
 
 template <typename T>
 __global__ void preprocess_kernel(const float* __restrict__ img, T* __restrict__ out, int in_h, int in_w,
-                                  int out_h, int out_w, int Hp, int Wp) {
+                                  int out_h, int out_w, int Hp, int Wp, size_t img_stride) {
     typedef typename Vec16<T>::type V;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= Wp) return;
+    img += (size_t)blockIdx.z * img_stride;                                // image blockIdx.z of a same-shape batch
+    out += (size_t)blockIdx.z * Hp * Wp * Vec16<T>::N;
     float v[3] = {0.f, 0.f, 0.f};
     if (y < out_h && x < out_w) {
         const float mean[3] = {0.485f, 0.456f, 0.406f};
@@ -204,10 +206,12 @@ inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
 }
 
 template <typename T>
-int preprocess(const float* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, void* stream) {
-    dim3 grid((Wp + 255) / 256, Hp);
+int preprocess(const float* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, void* stream,
+               int n = 1, size_t img_stride = 0) {
+    if (n < 1 || n > 65535) return (int)hipErrorInvalidValue;
+    dim3 grid((Wp + 255) / 256, Hp, n);
     hipLaunchKernelGGL(preprocess_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, img, (T*)out, in_h, in_w, out_h,
-                       out_w, Hp, Wp);
+                       out_w, Hp, Wp, img_stride);
     return (int)hipGetLastError();
 }
 
@@ -253,6 +257,15 @@ int seam_preprocess_f32(const float* img, float* out, int in_h, int in_w, int ou
 }
 int seam_preprocess_f16(const float* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, void* stream) {
     return preprocess<_Float16>(img, out, in_h, in_w, out_h, out_w, Hp, Wp, stream);
+}
+
+int seam_preprocess_batch_f32(const float* imgs, size_t img_stride, float* out, int n, int in_h, int in_w, int out_h, int out_w,
+                              int Hp, int Wp, void* stream) {
+    return preprocess<float>(imgs, out, in_h, in_w, out_h, out_w, Hp, Wp, stream, n, img_stride);
+}
+int seam_preprocess_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w, int out_h, int out_w,
+                              int Hp, int Wp, void* stream) {
+    return preprocess<_Float16>(imgs, out, in_h, in_w, out_h, out_w, Hp, Wp, stream, n, img_stride);
 }
 
 int seam_preprocess_u8(const uint8_t* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, int out_f16,

@@ -206,8 +206,7 @@ class FeaturePyramidNetwork(nn.Module):
         last = ops.conv2d(feats[3], inner[3])
         outs = [None, None, None, ops.conv2d(last, layer[3])]
         for i in (2, 1, 0):
-            lat = ops.conv2d(feats[i], inner[i])
-            last = ops.upsample_add_(lat, last)               # nearest top-down merge, in place
+            last = ops.conv2d_topdown(feats[i], inner[i], last)      # lateral 1x1 + nearest top-down merge, one launch
             outs[i] = ops.conv2d(last, layer[i])
         od = OrderedDict((str(i), o) for i, o in enumerate(outs))
         od["pool"] = ops.maxpool2d(outs[3], 1, 2, 0)          # LastLevelMaxPool
@@ -397,8 +396,16 @@ class MultiScaleRoIAlign(nn.Module):
         """-> NHWC [sum k_i, P, P, C] (the reference's NCHW view is produced at the model boundary)."""
         fl = [feats[k] for k in self.featmap_names]
         dev = fl[0].device
-        rois = torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i), device=dev), b.to(torch.float32)], 1)
-                          for i, b in enumerate(boxes)], 0).contiguous()
+        # [image index | box] rows: the index column is cached per (counts, device) -- one H2D copy the first time a
+        # batch shape is seen, then two cat launches per call instead of two tiny kernels per image
+        counts = tuple(int(b.shape[0]) for b in boxes)
+        key = (counts, str(dev))
+        if getattr(self, "_idx_key", None) != key:
+            self._idx = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.float32),
+                                                torch.tensor(counts, dtype=torch.int64)).view(-1, 1).to(dev)
+            self._idx_key = key
+        allb = torch.cat([b.to(torch.float32) for b in boxes], 0) if len(boxes) > 1 else boxes[0].to(torch.float32)
+        rois = torch.cat([self._idx, allb.view(-1, 4)], 1).contiguous()
         scales = self.infer_scales([f.shape[1:3] for f in fl], image_sizes)
         k_min = int(round(-math.log2(scales[0])))
         return ops.roi_align(fl, rois, scales, self.output_size, self.sampling_ratio, k_min)

@@ -242,8 +242,10 @@ class VideoMatchRCNN(nn.Module):
         feats, sizes, orig, padded = self.extract_features(list(images))
         rpn_out = self.rpn.head(list(feats.values())) if run_rpn_head else None
         dev = feats["0"].device
-        result = [dict(boxes=b.to(dev).to(torch.float32), labels=torch.ones(len(b), dtype=torch.int64, device=dev),
-                       scores=torch.ones(len(b), device=dev)) for b in rois]
+        counts = [len(b) for b in rois]
+        labels = torch.ones(sum(counts), dtype=torch.int64, device=dev).split(counts)      # one fill, per-image views
+        scores = torch.ones(sum(counts), device=dev).split(counts)
+        result = [dict(boxes=b.to(dev).to(torch.float32), labels=l, scores=s) for b, l, s in zip(rois, labels, scores)]
         result = self.roi_heads.match_branch(feats, result, sizes)
         return result, feats, rpn_out
 

@@ -339,6 +339,40 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     return y
 
 
+def conv2d_topdown(x: torch.Tensor, pc: PackedConv, top: torch.Tensor) -> torch.Tensor:
+    """FPN top-down merge [TV]: conv(x) + nearest-upsample(top) -> NHWC.  Exact-fp32 weights: ONE launch (the coarse map is
+    added in the conv epilogue, ``seam_conv2d_upres_f32``); other precisions: conv + ``upsample_add_``.  Both forms round
+    identically."""
+    if pc.dtype != F32 or pc.K % 4:
+        return upsample_add_(conv2d(x, pc), top)
+    x = _req(x, None, "x")
+    x, top = _req(x, F32, "x"), _req(top, F32, "top")
+    n, h, w, c = x.shape
+    if c != pc.Cstore:
+        raise ValueError(f"conv2d_topdown: input has {c} channels, weights packed for {pc.Cstore}")
+    ho = (h + 2 * pc.pad - pc.R) // pc.stride + 1
+    wo = (w + 2 * pc.pad - pc.S) // pc.stride + 1
+    if top.dim() != 4 or top.shape[0] != n or top.shape[3] != pc.K:
+        raise ValueError("conv2d_topdown: top must be NHWC [N,Ht,Wt,K]")
+    y = torch.empty((n, ho, wo, pc.K), dtype=F32, device=x.device)
+    trace = CONV_TRACE
+    if trace is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib = _native.lib()
+    _native.check(lib.seam_conv2d_upres_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(top), _ptr(y),
+                                            n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, top.shape[1], top.shape[2], 0,
+                                            _stream()), "seam_conv2d_upres_f32")
+    if trace is not None:
+        e1.record()
+        tile = lib.seam_conv_tile_prec(0, n * ho * wo, pc.K)
+        trace.append((f"conv_igemm<float,{tile // 1000},{tile % 1000}>",
+                      2.0 * n * ho * wo * pc.K * pc.R * pc.S * (pc.Cin or pc.Cstore), e0, e1,
+                      (n, h, w, c, pc.K, pc.R, pc.stride),
+                      float(4 * (x.numel() + pc.w.numel() + y.numel() + top.numel()))))
+    return y
+
+
 def linear(x: torch.Tensor, pc: PackedConv, relu: bool = False, out_f32: bool = False) -> torch.Tensor:
     """[M,C] x packed [K,C] -> [M,K] through the conv kernel (1x1 on a 1x1 map)."""
     m, c = x.shape
@@ -356,6 +390,18 @@ def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, 
     cs = 4 if dtype == F32 else 8
     out = torch.empty((len(images), hp, wp, cs), dtype=dtype, device=images[0].device)
     fn = lib.seam_preprocess_f32 if dtype == F32 else lib.seam_preprocess_f16
+    # the frames of one clip tensor (a list of same-shape fp32 views at a constant stride): one launch for the batch
+    n = len(images)
+    if n > 1 and n <= 65535 and all(i.dtype == F32 and i.dim() == 3 and i.shape == images[0].shape and i.is_contiguous()
+                                     and i.is_cuda for i in images) \
+            and images[0].shape[0] == 3 and all(tuple(s) == tuple(sizes[0]) for s in sizes):
+        p0 = images[0].data_ptr()
+        step = images[1].data_ptr() - p0
+        if step > 0 and step % 4 == 0 and all(im.data_ptr() == p0 + k * step for k, im in enumerate(images)):
+            fb = lib.seam_preprocess_batch_f32 if dtype == F32 else lib.seam_preprocess_batch_f16
+            _native.check(fb(C.c_void_p(p0), step // 4, _ptr(out), n, images[0].shape[1], images[0].shape[2], sizes[0][0],
+                             sizes[0][1], hp, wp, _stream()), "seam_preprocess_batch")
+            return out
     for i, (img, (oh, ow)) in enumerate(zip(images, sizes)):
         if img.dtype == torch.uint8:        # extension: raw HWC RGB frame, ToTensor fused (row f4)
             img = _req(img, torch.uint8, "image")

@@ -151,6 +151,41 @@ def test_maxpool_upsample_transpose_avgpool(ops):
     assert_close(ops.avgpool(nhwc(a).to(d)), F.avg_pool2d(a, 6).flatten(1), rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [((3, 64, 26, 34), (13, 17)), ((5, 128, 25, 25), (13, 13)), ((2, 512, 50, 50), (25, 25)),
+                                   ((9, 64, 13, 13), (7, 7))])
+def test_conv_topdown_fused(ops, shape):
+    """Lateral 1x1 conv + nearest top-down merge in one launch == conv followed by upsample_add_ (bit-exact: same
+    rounding order) == the torch reference (FPN forward [TV])."""
+    d = dev()
+    (n, c, h, w), (ht, wt) = shape
+    x, top = rnd(60, (n, c, h, w)), rnd(61, (n, 256, ht, wt))
+    wgt, b = rnd(62, (256, c, 1, 1), "w") / (c ** 0.5), rnd(63, (256,), "b")
+    pc = ops.pack_conv(wgt.to(d), b.to(d))
+    got = ops.conv2d_topdown(nhwc(x).to(d), pc, nhwc(top).to(d))
+    two = ops.upsample_add_(ops.conv2d(nhwc(x).to(d), pc), nhwc(top).to(d))
+    assert torch.equal(got, two)
+    ref = F.conv2d(x, wgt, b) + F.interpolate(top, size=(h, w), mode="nearest")
+    assert_close(got.permute(0, 3, 1, 2), ref)
+
+
+def test_preprocess_batched_clip_tensor(ops):
+    """The frames of one clip tensor (same-shape views at a constant stride) go through ONE launch; identical to the
+    per-image launches."""
+    d = dev()
+    from seam_match_rcnn_amd.models.detection import resized_size
+    clip = torch.from_numpy(synth.uniform(synth.stream_id(64, "clip"), (5, 3, 60, 90))).to(d)
+    sz = [resized_size(60, 90, 96, 160)[:2]] * 5
+    hp, wp = 96, 160
+    batched = ops.preprocess(list(clip.unbind(0)), sz, hp, wp)
+    single = torch.cat([ops.preprocess([clip[i].clone()], sz[:1], hp, wp) for i in range(5)])
+    assert torch.equal(batched, single)
+    # every other frame: still a constant stride
+    strided = ops.preprocess(list(clip[::2].unbind(0)), sz[:3], hp, wp)
+    assert torch.equal(strided, single[::2])
+    ref, _ = OD.transform(list(clip.cpu().unbind(0)), min_size=96, max_size=160)
+    assert_close(batched[..., :3].permute(0, 3, 1, 2), ref, atol_scale=1e-5)
+
+
 def test_roi_align_multiscale(ops):
     d = dev()
     sizes = [(200, 200)] * 2
