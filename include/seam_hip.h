@@ -299,6 +299,24 @@ int seam_conv3x3_wino_f32(const float* x, const float* u_packed, const float* sc
                           seam_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Winograd F(2x4,3x3) convolution, fp32 MFMA (csrc/seam_wino24.hip): the same layers and the same contract as
+ * seam_conv3x3_wino_f32, with output tiles of 2 rows x 4 columns (F(2,3) down the rows, F(4,3) with the points
+ * {0, +-1, +-2, inf} along the columns): 24 multiplies per 8 outputs -- 3x fewer matrix-core issues than
+ * seam_conv2d_f32, 1.33x fewer than seam_conv3x3_wino_f32; rounding ~2x that of F(2x2,3x3) (~1e-6 of the output
+ * scale).  u_packed: seam_wino24_weight_floats(K, Cstore) floats from seam_pack_conv_weight_wino24_f32 (U = G2 g G4t in
+ * fp64, rounded once, MFMA fragment order).  seam_wino_issue_slots / seam_wino24_issue_slots: MFMA work of a launch
+ * (block tile slots x positions) for the host's choice between the two forms (maps whose width is not a multiple of 4
+ * can favour F(2x2)). */
+long long seam_wino24_weight_floats(int K, int Cstore);
+long long seam_wino24_issue_slots(int N, int H, int W, int C, int K, int pad);
+long long seam_wino_issue_slots(int N, int H, int W, int C, int K, int pad);
+int seam_pack_conv_weight_wino24_f32(const float* w, float* u_packed, int K, int Cin, int Cstore, int mode,
+                                     seam_stream_t stream);
+int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* scale, const float* shift,
+                            const float* residual, float* y, int N, int H, int W, int C, int K, int pad, int relu,
+                            seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Gradient kernels of the match heads: the grad-enabled pass of the training loop,
  * stuffs/engine.py:120-121,158-168,183-185 -> MatchPredictor / TemporalAggregationNLB in .train()
  * (models/match_head.py:66-76,90-169,339).  fp32, fixed-order reductions (bit-reproducible).

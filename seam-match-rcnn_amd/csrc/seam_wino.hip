@@ -646,6 +646,16 @@ int seam_wino_slot_fill_pct(int N, int H, int W, int C, int K, int pad) {
     return (int)(100.0 * tiles / ((double)blocks * 32 * mt));
 }
 
+/* MFMA issues of the launch in units of 32x32x8-channel position GEMMs (blocks x 32*MT tile slots x 16 positions; 0 =
+ * unsupported) -- compared with seam_wino24_issue_slots to pick the cheaper Winograd form per layer shape. */
+long long seam_wino_issue_slots(int N, int H, int W, int C, int K, int pad) {
+    WinoArgs a;
+    int mt;
+    long blocks;
+    if (wino_plan(a, N, H, W, C, K, pad, mt, blocks)) return 0;
+    return (long long)blocks * 32 * mt * 16;
+}
+
 int seam_wino_tile_variant(int N, int H, int W, int C, int K, int pad) {     // MT of conv3x3_wino<MT> the launcher picks (0: unsupported)
     WinoArgs a;
     int mt;

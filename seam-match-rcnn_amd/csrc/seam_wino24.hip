@@ -1,0 +1,597 @@
+// seam_wino24.hip -- Winograd F(2x4,3x3) convolution on the gfx950 fp32 matrix cores.
+//
+// The second Winograd kernel of the path: output tiles of 2 rows x 4 columns from 4 x 6 input tiles, i.e. F(2,3) down
+// the rows (as seam_wino.hip) and F(4,3) along the columns: 24 multiplies per 8 outputs = 3 per output instead of
+// 4 (F(2x2,3x3)) or 9 (direct) -- 3x fewer MFMA issues than the implicit GEMM, 1.33x fewer than seam_wino.hip.
+//   Y = A2t [ (G2 g G4t) (.) (B2t d B4) ] A4   per tile, summed over input channels = 24 independent GEMMs
+//   M_p[tile, n] = sum_c V_p[tile, c] * U_p[n, c],  p = (xi in 0..3, nu in 0..5), all fp32 (v_mfma_f32_32x32x2_f32).
+// The F(4,3) half uses the points {0, +-1, +-2, inf}; its transforms multiply by 2, 4, 5, 8 (input / output side) and
+// 1/4, 1/6, 1/12, 1/24 (weights, computed in fp64 at pack time and rounded once): measured rounding ~2x that of
+// F(2x2,3x3), ~1e-6 of the output scale (tools/wino_bench.py).
+//
+// Mapping (same ideas as seam_wino.hip -- no operand goes through LDS):
+//   block = 4 waves; wave xi owns the six positions (xi, nu = 0..5) for 32 tiles x 32 output channels: 6 accumulator
+//   tiles of 32x32 (96 VGPRs), two blocks per CU.
+//   A operand: each wave computes ITS row of B2t d (two input rows per column) and the six column combinations in
+//     registers, directly in MFMA A-fragment layout, from the block's raw input patch -- the only LDS resident:
+//     (2*TY+2) x (4*TX+2) pixels x 8 channels per chunk, split by channel half and by x mod 4 so that the tile-strided
+//     ds_read_b128s are conflict free, double buffered, one barrier per 8-channel chunk.
+//   B operand: U packed in fragment order [n_tile][chunk][p][lane][4]; a wave streams its 6 KiB per chunk with coalesced
+//     buffer loads straight into registers.
+//   Registers are the scarce resource (96 accumulators): A and B fragments are SINGLE sets that roll -- the positions are
+//     walked in pairs (0,5), (1,2), (3,4) (the pairs that share sub-expressions of B4t); as soon as the 8 MFMAs of a
+//     pair are issued, its A fragments are overwritten with those of the next chunk and its weight loads for the next
+//     chunk are issued (16 MFMA slots ahead of their use).
+//   Epilogue: the nu half of the output transform (A4t: 6 -> 4) in registers, the xi half (A2t: 4 -> 2) through a
+//     32 KiB LDS exchange in two passes, scale / shift (+ residual, ReLU), 16-byte NHWC stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr unsigned kOob = 0x80000000u;
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x4 fma4(f32x2 c, f32x4 b, f32x4 a) {        // a + c * b
+    const f32x2 lo = pk_fma(c, __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(a, a, 0, 1));
+    const f32x2 hi = pk_fma(c, __builtin_shufflevector(b, b, 2, 3), __builtin_shufflevector(a, a, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_add(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_add(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    const f32x2 lo = pk_sub(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_sub(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
+struct Wino24Args {
+    const float* x;
+    const float* u;       // packed transformed weights
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int N, H, W, C, K;
+    int Ho, Wo, pad, relu;
+    // Up to three regions tile an image (main region + right strip + bottom strip), each with its own block patch shape,
+    // or -- stacked mode, maps narrower than a block -- TY[0] consecutive tile rows of the whole batch per block
+    // (see seam_wino.hip; identical conventions, only the tile is 4 output columns wide).
+    int nreg;
+    int rx0[3], ry0[3];
+    int rxe[3], rye[3];
+    int TX[3], TY[3];     // tiles per block patch (TX*TY <= 32)
+    int bx[3], by[3];
+    int per_img;
+    int stack;
+    int tiles_y;
+    int PH;
+    int G;
+    int tiles_n;          // K / 32
+    int nchunks;          // C / 8
+};
+
+constexpr int NPIXMAX = 384;                       // raw patch pixels per buffer (3 x 16-byte loads per thread per chunk)
+constexpr int NI = (2 * NPIXMAX + 255) / 256;
+constexpr int ENTMAX = 416;                        // 16-byte LDS entries per channel half (rows x 4 phases x (TX+1))
+constexpr int RAWB = (2 * ENTMAX + 1) * 16;        // bytes per raw buffer (+1 dump slot for idle loader lanes)
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
+    __shared__ __attribute__((aligned(16))) char raw[2][RAWB];
+    __shared__ __attribute__((aligned(16))) float ex[4 * 2 * 32 * 32];      // epilogue exchange [xi][b][tile][n]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int xi = tid >> 6;
+
+    // ---- XCD-aware tile id (bijective) ----------------------------------------------------------------------------
+    const int nblk = gridDim.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int q8 = nblk >> 3, rem8 = nblk & 7;
+    const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
+    const int tm = tile / p.tiles_n;
+    const int tn = tile - tm * p.tiles_n;
+    const int per_img = p.per_img;
+    int rb = tm - (tm / per_img) * per_img;
+    int reg = 0;
+    if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
+        rb -= p.bx[0] * p.by[0];
+        reg = 1;
+        if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
+    }
+    const int TX = p.TX[reg], TY = p.TY[reg];
+    const int byi = rb / p.bx[reg];
+    const int bxi = rb - byi * p.bx[reg];
+    const int tys = p.tiles_y, pitch = 2 * tys + 2;
+    const int R0 = tm * TY;                                // stacked mode: first tile row (global) of this block
+    const int n_img = p.stack ? R0 / tys : tm / per_img;   // first image of this block
+    const int prow0 = p.stack ? 2 * (R0 - n_img * tys) : 0;
+    const int n_here = min(p.G, p.N - n_img);
+    const int ty0 = p.stack ? 0 : p.ry0[reg] + byi * TY, tx0 = p.stack ? 0 : p.rx0[reg] + bxi * TX;
+    const int tye = p.rye[reg], txe = p.rxe[reg];
+    const int iy0 = 2 * ty0 - p.pad, ix0 = 4 * tx0 - p.pad; // top-left input pixel of the raw patch (regions mode)
+
+    const int PW = 4 * TX + 2, PH = p.stack ? p.PH : 2 * TY + 2;
+    const int NPIX = PW * PH;
+    const int HS = TX + 1;                                 // 16-byte entries per (patch row, x mod 4)
+    const int NENT = 4 * HS * PH;                          // entries per channel half
+    const int nslots = TX * TY;
+    auto slot = [&](int id, int& g, int& ty, int& tx, int& prow) -> bool {
+        const int r = id / TX;
+        tx = tx0 + (id - r * TX);
+        if (p.stack) {
+            const int R = R0 + r;
+            const int n = R / tys;
+            g = n - n_img;
+            ty = R - n * tys;
+            prow = pitch * g + 2 * ty - prow0;
+            return id < nslots && n < p.N;
+        }
+        g = 0;
+        ty = ty0 + r;
+        prow = 2 * r;
+        return id < nslots && ty < tye && tx < txe;
+    };
+
+    // ---- raw patch loader -----------------------------------------------------------------------------------------
+    const size_t img_bytes = (size_t)p.H * p.W * p.C * 4;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.x + (size_t)n_img * img_bytes), 0, (int)(img_bytes * n_here), 0x00020000);
+    unsigned goff[NI];
+    int loff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = tid + 256 * i;
+        const int half = idx & 1;
+        const int pix = idx >> 1;
+        const bool ok = pix < NPIX;
+        const int v = pix / PW;                            // patch row
+        const int px = pix - v * PW;
+        int g = 0, gy = iy0 + v;
+        if (p.stack) {
+            const int vr = prow0 + v;
+            g = vr / pitch;
+            gy = vr - g * pitch - p.pad;
+        }
+        const int gx = ix0 + px;
+        const bool inb = ok && g < n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        goff[i] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + half * 4) * 4) : kOob;
+        loff[i] = ok ? (half * NENT + (v * 4 + (px & 3)) * HS + (px >> 2)) * 16 : 2 * ENTMAX * 16;
+    }
+    const int last_chunk = p.nchunks - 1;
+    f32x4 rset[2][NI];
+    auto load_raw = [&](f32x4 (&rs)[NI], int chunk) {
+        const int c = chunk < last_chunk ? chunk : last_chunk;     // past the end: re-read the last chunk (never used)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            rs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[i], c * 32, 0));
+    };
+    auto store_raw = [&](const f32x4 (&rs)[NI], int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(&raw[buf][loff[i]]) = rs[i];
+    };
+
+    // ---- weight fragments: [tn][chunk][p = 6*xi + nu][lane][4] ----------------------------------------------------
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.u + (size_t)tn * p.nchunks * 24576), 0, p.nchunks * 24576, 0x00020000);
+    const int uoff = (xi * 6 * 64 + lane) * 16;
+    f32x4 bf[6];
+    auto load_b = [&](int nu, int chunk) {
+        const int c = chunk < last_chunk ? chunk : last_chunk;
+        bf[nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff + nu * 1024, c * 24576, 0));
+    };
+
+    // ---- input transform --------------------------------------------------------------------------------------------
+    // rows (B2t, this wave's xi): xi0: d0 - d2, xi1: d1 + d2, xi2: d2 - d1, xi3: d1 - d3   =>  T_j = d[ra][j] + cb * d[rb][j]
+    // columns (B4t over j = 0..5):
+    //   V0 = 4 T0 - 5 T2 + T4            V5 = 4 T1 - 5 T3 + T5
+    //   V1 = (T4 - 4 T2) + (T3 - 4 T1)   V2 = (T4 - 4 T2) - (T3 - 4 T1)
+    //   V3 = (T4 - T2) + 2 (T3 - T1)     V4 = (T4 - T2) - 2 (T3 - T1)
+    const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1;
+    const int rbw = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
+    const float cb = xi == 1 ? 1.f : -1.f;
+    const int row_bytes = 4 * HS * 16;                      // one patch row = four x-phase rows
+    int rbase;
+    {
+        int g, ty, tx, prow;
+        if (!slot(lane & 31, g, ty, tx, prow)) slot(0, g, ty, tx, prow);    // idle slots read tile 0 (never stored)
+        rbase = ((lane >> 5) * NENT + prow * 4 * HS + (tx - tx0)) * 16;
+    }
+    const int oa = ra * row_bytes, ob = rbw * row_bytes;
+    const int c1 = HS * 16;                                 // column j: phase (j & 3) at entry (j >> 2)
+    const f32x2 cb2 = {cb, cb};
+    const f32x2 k4 = {4.f, 4.f}, km5 = {-5.f, -5.f}, km4 = {-4.f, -4.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
+    f32x4 va[6];            // A fragments of the current chunk (rolling: overwritten pair by pair with the next chunk's)
+    f32x4 T0, T1, T2, T3, T4, T5;
+    f32x4 xa[3], xb[3];
+    auto rdA = [&](int buf) {            // columns 0, 2, 4
+        const char* base = &raw[buf][rbase];
+        xa[0] = *reinterpret_cast<const f32x4*>(base + oa);
+        xb[0] = *reinterpret_cast<const f32x4*>(base + ob);
+        xa[1] = *reinterpret_cast<const f32x4*>(base + oa + 2 * c1);
+        xb[1] = *reinterpret_cast<const f32x4*>(base + ob + 2 * c1);
+        xa[2] = *reinterpret_cast<const f32x4*>(base + oa + 16);
+        xb[2] = *reinterpret_cast<const f32x4*>(base + ob + 16);
+    };
+    auto rdB = [&](int buf) {            // columns 1, 3, 5
+        const char* base = &raw[buf][rbase];
+        xa[0] = *reinterpret_cast<const f32x4*>(base + oa + c1);
+        xb[0] = *reinterpret_cast<const f32x4*>(base + ob + c1);
+        xa[1] = *reinterpret_cast<const f32x4*>(base + oa + 3 * c1);
+        xb[1] = *reinterpret_cast<const f32x4*>(base + ob + 3 * c1);
+        xa[2] = *reinterpret_cast<const f32x4*>(base + oa + c1 + 16);
+        xb[2] = *reinterpret_cast<const f32x4*>(base + ob + c1 + 16);
+    };
+    auto cTA = [&]() { T0 = fma4(cb2, xb[0], xa[0]); T2 = fma4(cb2, xb[1], xa[1]); T4 = fma4(cb2, xb[2], xa[2]); };
+    auto cTB = [&]() { T1 = fma4(cb2, xb[0], xa[0]); T3 = fma4(cb2, xb[1], xa[1]); T5 = fma4(cb2, xb[2], xa[2]); };
+    auto cV05 = [&]() {
+        va[0] = fma4(km5, T2, fma4(k4, T0, T4));
+        va[5] = fma4(km5, T3, fma4(k4, T1, T5));
+    };
+    auto cV12 = [&]() {
+        const f32x4 a = fma4(km4, T2, T4), bq = fma4(km4, T1, T3);
+        va[1] = add4(a, bq);
+        va[2] = sub4(a, bq);
+    };
+    auto cV34 = [&]() {
+        const f32x4 c = sub4(T4, T2), d = sub4(T3, T1);
+        va[3] = fma4(k2, d, c);
+        va[4] = fma4(km2, d, c);
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define MF(nu, kk) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[nu][kk], bf[nu][kk], acc[nu], 0, 0, 0)
+
+    // ---- prologue -------------------------------------------------------------------------------------------------
+    load_raw(rset[0], 0);
+    load_raw(rset[1], 1);
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) load_b(nu, 0);
+    store_raw(rset[0], 0);
+    store_raw(rset[1], 1);
+    load_raw(rset[0], 2);
+    load_raw(rset[1], 3);
+    __syncthreads();
+    rdA(0); cTA(); rdB(0); cTB(); cV05(); cV12();     // V3, V4 of chunk 0 are made in its first slot
+    __syncthreads();                                  // chunk 0 overwrites raw[0] right away
+
+    // At the top of chunk t: raw[t&1] = patch(t) (already consumed), raw[(t+1)&1] = patch(t+1), rset[t&1] = patch(t+2) in
+    // flight, rset[(t+1)&1] = patch(t+3) in flight, bf = weights(t), va[0,5,1,2] = A fragments of chunk t, T0..T5 = the
+    // row transform of chunk t (V3, V4 still to be made from it).
+    auto chunk = [&](int t, int par) {
+        SB(); MF(0, 0); cV34();
+        SB(); MF(5, 0); store_raw(rset[par], par);
+        SB(); MF(0, 1); rdA(par ^ 1);
+        SB(); MF(5, 1); load_raw(rset[par], t + 4);
+        SB(); MF(0, 2); cTA();
+        SB(); MF(5, 2); rdB(par ^ 1);
+        SB(); MF(0, 3);
+        SB(); MF(5, 3); cTB();
+        SB(); MF(1, 0); cV05();
+        SB(); MF(2, 0); load_b(0, t + 1); load_b(5, t + 1);
+        SB(); MF(1, 1);
+        SB(); MF(2, 1);
+        SB(); MF(1, 2);
+        SB(); MF(2, 2);
+        SB(); MF(1, 3);
+        SB(); MF(2, 3);
+        SB(); MF(3, 0); cV12();
+        SB(); MF(4, 0); load_b(1, t + 1); load_b(2, t + 1);
+        SB(); MF(3, 1);
+        SB(); MF(4, 1);
+        SB(); MF(3, 2);
+        SB(); MF(4, 2);
+        SB(); MF(3, 3);
+        SB(); MF(4, 3); load_b(3, t + 1); load_b(4, t + 1);
+        SB();
+        __syncthreads();
+    };
+    for (int t = 0; t < p.nchunks; t += 2) {
+        chunk(t, 0);
+        if (t + 1 < p.nchunks) chunk(t + 1, 1);
+    }
+#undef SB
+#undef MF
+
+    // ---- epilogue: output transform + scale/shift (+ residual, ReLU) ------------------------------------------------
+    //   columns (A4t over nu): Y0 = m0+m1+m2+m3+m4, Y1 = (m1-m2) + 2(m3-m4), Y2 = (m1+m2) + 4(m3+m4), Y3 = (m1-m2) + 8(m3-m4) + m5
+    //   rows (A2t over xi, across the waves): y0 = q0+q1+q2, y1 = q1-q2-q3
+    const size_t out_img = (size_t)p.Ho * p.Wo * p.K * 4;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)p.y + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(p.res ? p.res : p.y) + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
+    const int et = tid >> 3;          // tile of the exchange this thread finishes
+    const int n4 = tid & 7;
+    const int ncol = tn * 32 + n4 * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + ncol);
+    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + ncol);
+    int g, tyt, txt, prow_unused;
+    const bool tile_ok = slot(et, g, tyt, txt, prow_unused) && g < n_here;
+    const int oy = 2 * tyt, ox = 4 * txt;
+#pragma unroll
+    for (int bp = 0; bp < 2; ++bp) {
+        __syncthreads();              // previous readers of `ex` are done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r];
+            float ya, yb;
+            if (bp == 0) {
+                ya = acc[0][r] + (m1 + m2) + (m3 + m4);
+                yb = (m1 - m2) + 2.f * (m3 - m4);
+            } else {
+                ya = (m1 + m2) + 4.f * (m3 + m4);
+                yb = (m1 - m2) + 8.f * (m3 - m4) + acc[5][r];
+            }
+            ex[((xi * 2 + 0) * 32 + row) * 32 + (lane & 31)] = ya;
+            ex[((xi * 2 + 1) * 32 + row) * 32 + (lane & 31)] = yb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(&ex[((1 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(&ex[((2 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q3 = *reinterpret_cast<const f32x4*>(&ex[((3 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
+            f32x4 yv[2];
+            yv[0] = q0 + q1 + q2;
+            yv[1] = q1 - q2 - q3;
+            const int oxx = ox + 2 * bp + bb;
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const bool ok = tile_ok && (oy + aa) < p.Ho && oxx < p.Wo;
+                const unsigned off = ok ? (unsigned)(((((g * p.Ho + oy + aa) * p.Wo) + oxx) * p.K + ncol) * 4) : kOob;
+                f32x4 v = yv[aa] * sc + sh;
+                if (p.res) {
+                    const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
+                    if (p.relu == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
+                    } else {
+                        v += rv;
+                    }
+                }
+                if (p.relu == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, off, 0, 0);
+            }
+        }
+    }
+}
+
+// OIHW fp32 [K, Cin, 3, 3] -> U = G2 g G4t in MFMA fragment order: [K/32][Cstore/8][24][64][4]
+//   element (tn, chunk, p = 6*xi + nu, lane, e) = U_p[n = 32*tn + (lane & 31)][c = 8*chunk + 4*(lane >> 5) + e]
+// mode 0: forward weights; mode 2: input-gradient weights (taps rotated 180 degrees, channels swapped), as in
+// seam_pack_conv_weight_f32.  fp64 arithmetic, one rounding.
+__global__ void wino24_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int K, int Cin, int Cstore, int mode) {
+    const int nch = Cstore / 8;
+    const size_t total = (size_t)(K / 32) * nch * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const size_t rest = i >> 6;
+        const int chunk = (int)(rest % nch);
+        const int tn = (int)(rest / nch);
+        const int n = tn * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = chunk * 8 + (lane >> 5) * 4 + e;
+            double g[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    float v = 0.f;
+                    if (c < Cin) v = mode == 2 ? w[(((size_t)c * K + n) * 3 + (2 - r)) * 3 + (2 - s)] : w[(((size_t)n * Cin + c) * 3 + r) * 3 + s];
+                    g[r][s] = (double)v;
+                }
+            double gg[4][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                gg[0][s] = g[0][s];
+                gg[1][s] = 0.5 * (g[0][s] + g[1][s] + g[2][s]);
+                gg[2][s] = 0.5 * (g[0][s] - g[1][s] + g[2][s]);
+                gg[3][s] = g[2][s];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double a0 = gg[q][0], a1 = gg[q][1], a2 = gg[q][2];
+                double uu[6];
+                uu[0] = a0 / 4.0;
+                uu[1] = -(a0 + a1 + a2) / 6.0;
+                uu[2] = -(a0 - a1 + a2) / 6.0;
+                uu[3] = a0 / 24.0 + a1 / 12.0 + a2 / 6.0;
+                uu[4] = a0 / 24.0 - a1 / 12.0 + a2 / 6.0;
+                uu[5] = a2;
+                const size_t base = ((((size_t)tn * nch + chunk) * 24 + q * 6) * 64 + lane) * 4 + e;
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu) out[base + (size_t)nu * 256] = (float)uu[nu];
+            }
+        }
+    }
+}
+
+// ---- block layout (32 tile slots of 2 x 4 outputs per block) --------------------------------------------------------
+struct Layout {
+    int nreg, G, stack, PH;
+    int rx0[3], ry0[3], rxe[3], rye[3], TX[3], TY[3], bx[3], by[3];
+    long per_img, blocks;      // blocks: per n-tile, for N images
+};
+
+constexpr int CAP = 32;
+
+inline bool patch_ok(int tx, int ty) {
+    return tx >= 1 && ty >= 1 && tx * ty <= CAP && (4 * tx + 2) * (2 * ty + 2) <= NPIXMAX && 4 * (tx + 1) * (2 * ty + 2) <= ENTMAX;
+}
+
+inline long best_uniform(int w, int h, int& TX, int& TY) {
+    long best = -1, best_cost = -1;
+    for (int ty = 1; ty <= CAP && ty <= h; ++ty)
+        for (int tx = 1; tx * ty <= CAP && tx <= w; ++tx) {
+            if (!patch_ok(tx, ty)) continue;
+            const long nb = (long)((w + tx - 1) / tx) * ((h + ty - 1) / ty);
+            const long cost = nb * 4096 + (4 * tx + 2) * (2 * ty + 2);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; TX = tx; TY = ty; }
+        }
+    return best;
+}
+
+inline Layout choose_layout(int N, int tiles_x, int tiles_y, size_t in_img_bytes, size_t out_img_bytes) {
+    Layout L;
+    L.nreg = 1; L.G = 1; L.stack = 0; L.PH = 0;
+    Layout S;
+    S.blocks = -1;
+    if (tiles_x <= CAP) {      // stacked candidate: TY consecutive tile rows of the batch at full width per block
+        const int t = tiles_y, pitch = 2 * t + 2, pw = 4 * tiles_x + 2;
+        for (int ty = CAP / tiles_x; ty >= 1; --ty) {
+            int phmax = 0, gmax = 0;
+            for (int b = 0; b < t; ++b) {
+                const int tyf = (int)(((long)b * ty) % t);
+                const int last = tyf + ty - 1;
+                const int gl = last / t, tyl = last - gl * t;
+                const int span = pitch * gl + 2 * tyl + 4 - 2 * tyf;
+                if (span > phmax) phmax = span;
+                if (gl + 1 > gmax) gmax = gl + 1;
+            }
+            if (phmax * pw > NPIXMAX || 4 * (tiles_x + 1) * phmax > ENTMAX) continue;
+            if ((size_t)gmax * in_img_bytes >= kOob || (size_t)gmax * out_img_bytes >= kOob) continue;
+            S.nreg = 1; S.stack = 1; S.PH = phmax; S.G = gmax;
+            S.rx0[0] = S.ry0[0] = 0; S.rxe[0] = tiles_x; S.rye[0] = tiles_y; S.TX[0] = tiles_x; S.TY[0] = ty; S.bx[0] = S.by[0] = 1;
+            S.per_img = 1;
+            S.blocks = ((long)N * t + ty - 1) / ty;
+            break;
+        }
+    }
+    long best_blocks = best_uniform(tiles_x, tiles_y, L.TX[0], L.TY[0]);
+    L.rx0[0] = L.ry0[0] = 0; L.rxe[0] = tiles_x; L.rye[0] = tiles_y;
+    L.bx[0] = (tiles_x + L.TX[0] - 1) / L.TX[0]; L.by[0] = (tiles_y + L.TY[0] - 1) / L.TY[0];
+    for (int ty = 1; ty <= CAP && ty <= tiles_y; ++ty)
+        for (int tx = 1; tx * ty <= CAP && tx <= tiles_x; ++tx) {
+            if (!patch_ok(tx, ty)) continue;
+            const int mx = tiles_x / tx, my = tiles_y / ty;
+            const int wm = mx * tx, hm = my * ty;
+            if (wm == 0 || hm == 0) continue;
+            Layout C;
+            C.G = 1; C.nreg = 1; C.stack = 0; C.PH = 0;
+            C.rx0[0] = 0; C.ry0[0] = 0; C.rxe[0] = wm; C.rye[0] = hm; C.TX[0] = tx; C.TY[0] = ty; C.bx[0] = mx; C.by[0] = my;
+            long nb = (long)mx * my;
+            if (wm < tiles_x) {
+                const int r = C.nreg++;
+                const long b = best_uniform(tiles_x - wm, tiles_y, C.TX[r], C.TY[r]);
+                C.rx0[r] = wm; C.ry0[r] = 0; C.rxe[r] = tiles_x; C.rye[r] = tiles_y;
+                C.bx[r] = (tiles_x - wm + C.TX[r] - 1) / C.TX[r]; C.by[r] = (tiles_y + C.TY[r] - 1) / C.TY[r];
+                nb += b;
+            }
+            if (hm < tiles_y) {
+                const int r = C.nreg++;
+                const long b = best_uniform(wm, tiles_y - hm, C.TX[r], C.TY[r]);
+                C.rx0[r] = 0; C.ry0[r] = hm; C.rxe[r] = wm; C.rye[r] = tiles_y;
+                C.bx[r] = (wm + C.TX[r] - 1) / C.TX[r]; C.by[r] = (tiles_y - hm + C.TY[r] - 1) / C.TY[r];
+                nb += b;
+            }
+            if (nb < best_blocks) {
+                best_blocks = nb;
+                L = C;
+            }
+        }
+    L.per_img = 0;
+    for (int r = 0; r < L.nreg; ++r) L.per_img += (long)L.bx[r] * L.by[r];
+    L.blocks = L.per_img * N;
+    if (S.blocks > 0 && S.blocks < L.blocks) return S;
+    return L;
+}
+
+inline bool wino_ok(int C, int K, int R, int S, int stride) { return R == 3 && S == 3 && stride == 1 && C % 8 == 0 && K % 32 == 0 && C >= 8; }
+
+int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long& blocks) {
+    if (!wino_ok(C, K, 3, 3, 1) || N <= 0) return (int)hipErrorInvalidValue;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.K = K;
+    a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2; a.pad = pad;
+    if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
+    if ((size_t)H * W * C * 4 >= kOob || (size_t)a.Ho * a.Wo * K * 4 >= kOob) return (int)hipErrorInvalidValue;
+    const int tiles_x = (a.Wo + 3) / 4, tiles_y = (a.Ho + 1) / 2;
+    const Layout pp = choose_layout(N, tiles_x, tiles_y, (size_t)H * W * C * 4, (size_t)a.Ho * a.Wo * K * 4);
+    a.tiles_n = K / 32;
+    a.nchunks = C / 8;
+    a.nreg = pp.nreg; a.G = pp.G; a.per_img = (int)pp.per_img;
+    a.stack = pp.stack; a.PH = pp.PH; a.tiles_y = tiles_y;
+    for (int r = 0; r < 3; ++r) {
+        const int q = r < pp.nreg ? r : 0;
+        a.rx0[r] = pp.rx0[q]; a.ry0[r] = pp.ry0[q]; a.rxe[r] = pp.rxe[q]; a.rye[r] = pp.rye[q];
+        a.TX[r] = pp.TX[q]; a.TY[r] = pp.TY[q]; a.bx[r] = pp.bx[q]; a.by[r] = pp.by[q];
+    }
+    blocks = pp.blocks * a.tiles_n;
+    if (blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+long long seam_wino24_weight_floats(int K, int Cstore) { return (long long)K * Cstore * 24; }
+
+int seam_pack_conv_weight_wino24_f32(const float* w, float* u_packed, int K, int Cin, int Cstore, int mode, void* stream) {
+    if (!wino_ok(Cstore, K, 3, 3, 1) || Cin > Cstore) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)(K / 32) * (Cstore / 8) * 64;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(wino24_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, u_packed, K, Cin, Cstore, mode);
+    return (int)hipGetLastError();
+}
+
+/* MFMA issues of the launch in units of 32x32x8-channel position GEMMs (blocks x 32 tile slots x 24 positions; 0 = unsupported):
+ * the figure ops.conv2d compares with seam_wino_issue_slots to pick the cheaper Winograd form for a layer shape. */
+long long seam_wino24_issue_slots(int N, int H, int W, int C, int K, int pad) {
+    Wino24Args a;
+    long blocks;
+    if (wino24_plan(a, N, H, W, C, K, pad, blocks)) return 0;
+    return (long long)blocks * 32 * 24;
+}
+
+int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* scale, const float* shift, const float* residual,
+                            float* y, int N, int H, int W, int C, int K, int pad, int relu, void* stream) {
+    Wino24Args a;
+    long blocks;
+    const int rc = wino24_plan(a, N, H, W, C, K, pad, blocks);
+    if (rc) return rc;
+    a.x = x; a.u = u_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.relu = relu;
+    hipLaunchKernelGGL(conv3x3_wino24, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

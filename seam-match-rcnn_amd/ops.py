@@ -58,6 +58,7 @@ class PackedConv:
     Cin: int = 0                    # real (unpadded) input channels: algorithmic FLOP accounting
     dtype: object = F32             # operand precision of the packed weights: torch.float32 | torch.float16 | BX3
     u: Optional[torch.Tensor] = None  # fp32 stride-1 3x3 layers: Winograd F(2x2,3x3) weights (seam_pack_conv_weight_wino_f32)
+    u24: Optional[torch.Tensor] = None  # ... and F(2x4,3x3) weights (seam_pack_conv_weight_wino24_f32)
 
 
 BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
@@ -76,6 +77,32 @@ def _pack_wino(lib, weight: torch.Tensor, K: int, cin: int, cs: int, mode: int) 
     _native.check(lib.seam_pack_conv_weight_wino_f32(_ptr(weight), _ptr(u), K, cin, cs, mode, _stream()),
                   "seam_pack_conv_weight_wino_f32")
     return u
+
+
+def _pack_wino24(lib, weight: torch.Tensor, K: int, cin: int, cs: int, mode: int) -> Optional[torch.Tensor]:
+    if not lib.seam_wino_supported(cs, K, 3, 3, 1):
+        return None
+    u = torch.empty((int(lib.seam_wino24_weight_floats(K, cs)),), dtype=F32, device=weight.device)
+    _native.check(lib.seam_pack_conv_weight_wino24_f32(_ptr(weight), _ptr(u), K, cin, cs, mode, _stream()),
+                  "seam_pack_conv_weight_wino24_f32")
+    return u
+
+
+# F(2x4,3x3) (csrc/seam_wino24.hip): 0 = never, 1 = where it issues fewer MFMAs than F(2x2,3x3) (x WINO24_MARGIN), 2 = always
+WINOGRAD24 = int(_os.environ.get("SEAM_WINOGRAD24", "1"))
+WINO24_MARGIN = float(_os.environ.get("SEAM_WINO24_MARGIN", "0.85"))
+_WINO24 = {}
+
+
+def _wino24_pays(lib, n, h, w, c, k, pad) -> bool:
+    if WINOGRAD24 >= 2:
+        return True
+    key = (n, h, w, c, k, pad)
+    f = _WINO24.get(key)
+    if f is None:
+        s24, s22 = int(lib.seam_wino24_issue_slots(n, h, w, c, k, pad)), int(lib.seam_wino_issue_slots(n, h, w, c, k, pad))
+        f = _WINO24[key] = s24 > 0 and s24 <= WINO24_MARGIN * s22
+    return f
 
 
 WINO_MIN_FILL = int(_os.environ.get("SEAM_WINO_MIN_FILL", "55"))    # % of tile slots in use below which the implicit GEMM wins
@@ -121,7 +148,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
     epv = 8 if dtype == F16 else 4
     cs = cstore if cstore is not None else ((cin + epv - 1) // epv) * epv
     rows = lib.seam_conv_rows_padded(K)
-    u = None
+    u = u24 = None
     if dtype == F32:
         kred = lib.seam_conv_kred(cs, R, S)
         wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
@@ -129,6 +156,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
                       "seam_pack_conv_weight_f32")
         if wino and mode == 0 and R == 3 and S == 3 and stride == 1:
             u = _pack_wino(lib, weight, K, cin, cs, 0)
+            u24 = _pack_wino24(lib, weight, K, cin, cs, 0) if u is not None else None
     elif dtype == BX3:
         kred = lib.seam_conv_kred(cs, R, S)
         wp = torch.empty((rows, kred), dtype=F32, device=weight.device)      # opaque: [32 hi | 32 lo] bf16 per 128-byte row-chunk
@@ -154,7 +182,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         shift = shift.contiguous()
     elif bias is not None:
         shift = bias.contiguous()
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u)
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24)
 
 
 def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -> PackedConv:
@@ -174,7 +202,8 @@ def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -
     _native.check(lib.seam_pack_conv_weight_f32(_ptr(weight), _ptr(wp), cin, cout, R, S, cout, 2, _stream()),
                   "seam_pack_conv_weight_f32")
     u = _pack_wino(lib, weight, cin, cout, cout, 2) if (wino and R == 3) else None
-    return PackedConv(wp, None, None, cin, cout, R, S, 1, R - 1 - pad_fwd, cout, F32, u)
+    u24 = _pack_wino24(lib, weight, cin, cout, cout, 2) if u is not None else None
+    return PackedConv(wp, None, None, cin, cout, R, S, 1, R - 1 - pad_fwd, cout, F32, u, u24)
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, R: int, S: int, stride: int = 1, pad: int = 0) -> torch.Tensor:
@@ -307,7 +336,11 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         e0.record()
     lib = _native.lib()
     wino = pc.dtype == F32 and pc.u is not None and WINOGRAD and _wino_pays(lib, n, h, w, c, pc.K, pc.pad)
-    if wino:
+    wino24 = wino and pc.u24 is not None and WINOGRAD24 and _wino24_pays(lib, n, h, w, c, pc.K, pc.pad)
+    if wino24:
+        _native.check(lib.seam_conv3x3_wino24_f32(_ptr(x), _ptr(pc.u24), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
+                                                  n, h, w, c, pc.K, pc.pad, int(relu), _stream()), "seam_conv3x3_wino24_f32")
+    elif wino:
         _native.check(lib.seam_conv3x3_wino_f32(_ptr(x), _ptr(pc.u), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                                 n, h, w, c, pc.K, pc.pad, int(relu), _stream()), "seam_conv3x3_wino_f32")
     elif pc.dtype == F32:
@@ -325,7 +358,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     if trace is not None:
         e1.record()
         tile = lib.seam_conv_tile_prec(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K)
-        if wino:
+        if wino24:
+            variant = "conv3x3_wino24"
+        elif wino:
             variant = f"conv3x3_wino<{lib.seam_wino_tile_variant(n, h, w, c, pc.K, pc.pad)}>"
         elif pc.dtype == BX3:
             variant = f"conv_igemm_bx3<{tile // 1000},{tile % 1000}>"

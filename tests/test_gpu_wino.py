@@ -1,4 +1,4 @@
-"""GPU parity of the Winograd F(2x2,3x3) kernel (csrc/seam_wino.hip) through the C ABI: vs the fp32 CPU oracle
+"""GPU parity of the Winograd kernels -- F(2x2,3x3) (csrc/seam_wino.hip) and F(2x4,3x3) (csrc/seam_wino24.hip) -- through the C ABI: vs the fp32 CPU oracle
 (torch conv2d = the ATen kernel the reference dispatches) and vs the implicit-GEMM kernel on the same inputs."""
 import math
 
@@ -22,10 +22,13 @@ def nhwc(x):
 @pytest.fixture(scope="module")
 def ops():
     import seam_match_rcnn_amd.ops as ops
-    saved = ops.WINO_MIN_FILL
+    saved = ops.WINO_MIN_FILL, ops.WINOGRAD24
     ops.WINO_MIN_FILL = 0            # force the Winograd kernel on every eligible shape, however poorly it fills its tiles
     yield ops
-    ops.WINO_MIN_FILL = saved
+    ops.WINO_MIN_FILL, ops.WINOGRAD24 = saved
+
+
+FORMS = [pytest.param(0, id="F2x2"), pytest.param(2, id="F2x4")]     # ops.WINOGRAD24: 0 = never, 2 = always
 
 
 WINO_CASES = [
@@ -50,9 +53,11 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_wino_vs_oracle(ops, case):
+def test_wino_vs_oracle(ops, case, form):
     n, c, h, w, k, pad, bn, res, relu = case
+    ops.WINOGRAD24 = form
     x = rnd(31, (n, c, h, w))
     wt = rnd(32, (k, c, 3, 3), "w") * (1.0 / math.sqrt(c * 9))
     bias = None if bn else rnd(33, (k,), "b") * 0.1
@@ -74,7 +79,7 @@ def test_wino_vs_oracle(ops, case):
     d = torch.device("cuda:0")
     pc = ops.pack_conv(wt.to(d), None if bias is None else bias.to(d), None if bnp is None else tuple(t.to(d) for t in bnp),
                        stride=1, pad=pad)
-    assert pc.u is not None, "layer should be Winograd-eligible"
+    assert pc.u is not None and pc.u24 is not None, "layer should be Winograd-eligible"
     xin = nhwc(x).to(d)
     rin = None if resid is None else nhwc(resid).to(d)
     saved = ops.WINOGRAD
@@ -94,8 +99,10 @@ def test_wino_vs_oracle(ops, case):
     assert float((yw - yd).abs().max()) <= 2e-5 * scale, f"winograd vs implicit GEMM: {float((yw - yd).abs().max()):.3e} (scale {scale:.3e})"
 
 
-def test_wino_dgrad_weights(ops):
+@pytest.mark.parametrize("form", FORMS)
+def test_wino_dgrad_weights(ops, form):
     """mode 2 pack (input-gradient weights: taps rotated, channels swapped) with the ReLU-mask epilogue (relu = 2)."""
+    ops.WINOGRAD24 = form
     d = torch.device("cuda:0")
     wt = rnd(41, (64, 96, 3, 3), "w") / math.sqrt(96 * 9)        # forward conv 96 -> 64
     dy = rnd(42, (2, 64, 12, 10), "dy")
@@ -113,8 +120,10 @@ def test_wino_dgrad_weights(ops):
     assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
 
 
-def test_wino_batch_invariance_and_determinism(ops):
+@pytest.mark.parametrize("form", FORMS)
+def test_wino_batch_invariance_and_determinism(ops, form):
     """Each image's result is independent of the batch it rides in, and repeat launches are bit-identical."""
+    ops.WINOGRAD24 = form
     d = torch.device("cuda:0")
     x = nhwc(rnd(51, (5, 256, 26, 30))).to(d)
     wt = (rnd(52, (256, 256, 3, 3), "w") / 48.0).to(d)
