@@ -194,7 +194,10 @@ def main():
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     **({"mfma_passes_per_product": 3, "issued_frac": round(3 * achieved / peak, 4)} if args.dtype == "bf16x3" else {}),
-                    **({"algorithm": "Winograd F(2x2,3x3): 16 MFMA multiplies per 2x2 output tile and channel pair instead of 36, "
+                    **({"algorithm": "Winograd F(2x4,3x3): 24 MFMA multiplies per 2x4 output tile and channel pair instead of 72, "
+                                     "so `achieved` (ALGORITHMIC FLOP/s, 2*M*K*9*C per launch) can exceed the MFMA peak",
+                        "mfma_issued_frac": round(achieved / 3.0 / peak, 4)} if dom == "conv3x3_wino24" else
+                       {"algorithm": "Winograd F(2x2,3x3): 16 MFMA multiplies per 2x2 output tile and channel pair instead of 36, "
                                      "so `achieved` (ALGORITHMIC FLOP/s, 2*M*K*9*C per launch) can exceed the MFMA peak",
                         "mfma_issued_frac": round(achieved / 2.25 / peak, 4)} if dom.startswith("conv3x3_wino") else {}),
                     "traffic": pmc_traffic(dom) if args.dtype == "f32" else None,

@@ -57,6 +57,19 @@ __device__ __forceinline__ f32x4 fma4(f32x2 c, f32x4 b, f32x4 a) {        // a +
     const f32x2 hi = pk_fma(c, __builtin_shufflevector(b, b, 2, 3), __builtin_shufflevector(a, a, 2, 3));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
+// the same with a wave-uniform multiplier held in an SGPR pair (one scalar source per VOP3P): the constants of B4t cost no
+// VGPRs -- the register file is full (96 accumulators, two weight sets), and a VGPR temporary that aliases the
+// destination of an in-flight weight load makes hipcc wait for that load
+__device__ __forceinline__ f32x2 pk_fma_s(f32x2 cs, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(cs), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x4 fma4s(f32x2 cs, f32x4 b, f32x4 a) {      // a + cs * b
+    const f32x2 lo = pk_fma_s(cs, __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(a, a, 0, 1));
+    const f32x2 hi = pk_fma_s(cs, __builtin_shufflevector(b, b, 2, 3), __builtin_shufflevector(a, a, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 __device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) {
     const f32x2 lo = pk_add(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
     const f32x2 hi = pk_add(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
@@ -67,6 +80,11 @@ __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
     const f32x2 hi = pk_sub(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
+
+#ifndef SEAM_W24_ABL
+#define SEAM_W24_ABL 0      // kernel experiments (tools/experiments/wino24_abl.sh; operands keep the REAL data of chunks 0/1):
+                            // 1 no in-loop patch loads / LDS stores, 2 no in-loop weight loads, 4 no barrier, 8 no in-loop transforms
+#endif
 
 struct Wino24Args {
     const float* x;
@@ -96,7 +114,7 @@ struct Wino24Args {
 
 constexpr int NPIXMAX = 384;                       // raw patch pixels per buffer (3 x 16-byte loads per thread per chunk)
 constexpr int NI = (2 * NPIXMAX + 255) / 256;
-constexpr int ENTMAX = 416;                        // 16-byte LDS entries per channel half (rows x 4 phases x (TX+1))
+constexpr int ENTMAX = 448;                        // 16-byte LDS entries per channel half (row pairs x PR, see the kernel)
 constexpr int RAWB = (2 * ENTMAX + 1) * 16;        // bytes per raw buffer (+1 dump slot for idle loader lanes)
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
@@ -138,7 +156,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     const int PW = 4 * TX + 2, PH = p.stack ? p.PH : 2 * TY + 2;
     const int NPIX = PW * PH;
     const int HS = TX + 1;                                 // 16-byte entries per (patch row, x mod 4)
-    const int NENT = 4 * HS * PH;                          // entries per channel half
+    // A pair of patch rows (= one tile row step) takes PR entries, PR = 8 * HS rounded up to TX (mod 8): tile (r, tx) then
+    // sits at r * PR + tx = lane (mod 8) -- the eight lanes of a ds_read_b128 phase always hit eight different 16-byte
+    // bank groups, whatever the patch shape (without it tile rows alias: 8 * HS = 0 mod 8, two-way conflicts for TX < 8)
+    const int PR = 8 * HS + (TX & 7);
+    const int NENT = PR * ((PH + 1) >> 1);                 // entries per channel half
     const int nslots = TX * TY;
     auto slot = [&](int id, int& g, int& ty, int& tx, int& prow) -> bool {
         const int r = id / TX;
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         const int gx = ix0 + px;
         const bool inb = ok && g < n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         goff[i] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + half * 4) * 4) : kOob;
-        loff[i] = ok ? (half * NENT + (v * 4 + (px & 3)) * HS + (px >> 2)) * 16 : 2 * ENTMAX * 16;
+        loff[i] = ok ? (half * NENT + (v >> 1) * PR + ((v & 1) * 4 + (px & 3)) * HS + (px >> 2)) * 16 : 2 * ENTMAX * 16;
     }
     const int last_chunk = p.nchunks - 1;
     f32x4 rset[2][NI];
@@ -199,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.u + (size_t)tn * p.nchunks * 24576), 0, p.nchunks * 24576, 0x00020000);
     const int uoff = (xi * 6 * 64 + lane) * 16;
-    f32x4 bf[6];
-    auto load_b = [&](int nu, int chunk) {
+    f32x4 bfs[2][6];
+    auto load_b = [&](f32x4 (&bf)[6], int nu, int chunk) {
         const int c = chunk < last_chunk ? chunk : last_chunk;
         bf[nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff + nu * 1024, c * 24576, 0));
     };
@@ -213,15 +235,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     //   V3 = (T4 - T2) + 2 (T3 - T1)     V4 = (T4 - T2) - 2 (T3 - T1)
     const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1;
     const int rbw = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
-    const float cb = xi == 1 ? 1.f : -1.f;
-    const int row_bytes = 4 * HS * 16;                      // one patch row = four x-phase rows
+    const float cb = __builtin_amdgcn_readfirstlane(xi) == 1 ? 1.f : -1.f;      // wave-uniform: lives in an SGPR
     int rbase;
     {
         int g, ty, tx, prow;
         if (!slot(lane & 31, g, ty, tx, prow)) slot(0, g, ty, tx, prow);    // idle slots read tile 0 (never stored)
-        rbase = ((lane >> 5) * NENT + prow * 4 * HS + (tx - tx0)) * 16;
+        rbase = ((lane >> 5) * NENT + (prow >> 1) * PR + (tx - tx0)) * 16;      // prow is even
     }
-    const int oa = ra * row_bytes, ob = rbw * row_bytes;
+    const int oa = ((ra >> 1) * PR + (ra & 1) * 4 * HS) * 16, ob = ((rbw >> 1) * PR + (rbw & 1) * 4 * HS) * 16;
     const int c1 = HS * 16;                                 // column j: phase (j & 3) at entry (j >> 2)
     const f32x2 cb2 = {cb, cb};
     const f32x2 k4 = {4.f, 4.f}, km5 = {-5.f, -5.f}, km4 = {-4.f, -4.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
@@ -246,21 +267,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         xa[2] = *reinterpret_cast<const f32x4*>(base + oa + c1 + 16);
         xb[2] = *reinterpret_cast<const f32x4*>(base + ob + c1 + 16);
     };
-    auto cTA = [&]() { T0 = fma4(cb2, xb[0], xa[0]); T2 = fma4(cb2, xb[1], xa[1]); T4 = fma4(cb2, xb[2], xa[2]); };
-    auto cTB = [&]() { T1 = fma4(cb2, xb[0], xa[0]); T3 = fma4(cb2, xb[1], xa[1]); T5 = fma4(cb2, xb[2], xa[2]); };
+    auto cTA = [&]() { T0 = fma4s(cb2, xb[0], xa[0]); T2 = fma4s(cb2, xb[1], xa[1]); T4 = fma4s(cb2, xb[2], xa[2]); };
+    auto cTB = [&]() { T1 = fma4s(cb2, xb[0], xa[0]); T3 = fma4s(cb2, xb[1], xa[1]); T5 = fma4s(cb2, xb[2], xa[2]); };
     auto cV05 = [&]() {
-        va[0] = fma4(km5, T2, fma4(k4, T0, T4));
-        va[5] = fma4(km5, T3, fma4(k4, T1, T5));
+        va[0] = fma4s(km5, T2, fma4s(k4, T0, T4));
+        va[5] = fma4s(km5, T3, fma4s(k4, T1, T5));
     };
     auto cV12 = [&]() {
-        const f32x4 a = fma4(km4, T2, T4), bq = fma4(km4, T1, T3);
+        const f32x4 a = fma4s(km4, T2, T4), bq = fma4s(km4, T1, T3);
         va[1] = add4(a, bq);
         va[2] = sub4(a, bq);
     };
     auto cV34 = [&]() {
         const f32x4 c = sub4(T4, T2), d = sub4(T3, T1);
-        va[3] = fma4(k2, d, c);
-        va[4] = fma4(km2, d, c);
+        va[3] = fma4s(k2, d, c);
+        va[4] = fma4s(km2, d, c);
     };
 
     f32x16 acc[6];
@@ -270,13 +291,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
-#define MF(nu, kk) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[nu][kk], bf[nu][kk], acc[nu], 0, 0, 0)
+#define MF(nu, kk) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[nu][kk], bcur[nu][kk], acc[nu], 0, 0, 0)
 
     // ---- prologue -------------------------------------------------------------------------------------------------
     load_raw(rset[0], 0);
     load_raw(rset[1], 1);
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu) load_b(nu, 0);
+    for (int nu = 0; nu < 6; ++nu) load_b(bfs[0], nu, 0);
     store_raw(rset[0], 0);
     store_raw(rset[1], 1);
     load_raw(rset[0], 2);
@@ -288,40 +309,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     // At the top of chunk t: raw[t&1] = patch(t) (already consumed), raw[(t+1)&1] = patch(t+1), rset[t&1] = patch(t+2) in
     // flight, rset[(t+1)&1] = patch(t+3) in flight, bf = weights(t), va[0,5,1,2] = A fragments of chunk t, T0..T5 = the
     // row transform of chunk t (V3, V4 still to be made from it).
-    auto chunk = [&](int t, int par) {
-        SB(); MF(0, 0); cV34();
-        SB(); MF(5, 0); store_raw(rset[par], par);
-        SB(); MF(0, 1); rdA(par ^ 1);
-        SB(); MF(5, 1); load_raw(rset[par], t + 4);
-        SB(); MF(0, 2); cTA();
-        SB(); MF(5, 2); rdB(par ^ 1);
-        SB(); MF(0, 3);
-        SB(); MF(5, 3); cTB();
-        SB(); MF(1, 0); cV05();
-        SB(); MF(2, 0); load_b(0, t + 1); load_b(5, t + 1);
+#define A1(x) do { if (!(SEAM_W24_ABL & 1)) { x; } } while (0)
+#define A2(x) do { if (!(SEAM_W24_ABL & 2)) { x; } } while (0)
+#define A8(x) do { if (!(SEAM_W24_ABL & 8)) { x; } } while (0)
+    // Weights: two register sets, all six loads of chunk t+1 issued at the top of chunk t, BEFORE the patch loads -- the
+    // vector-memory counter retires in order, so a wait for a weight fragment also waits for every older load: with the
+    // weights first, the (HBM-latency) patch loads of chunk t are not forced to complete before the top of chunk t+2.
+    auto chunk = [&](int t, int par, f32x4 (&bcur)[6], f32x4 (&bnext)[6]) {
+        SB(); MF(0, 0); A8(cV34());
+        SB(); MF(5, 0); A8(rdA(par ^ 1));
+        SB(); MF(0, 1); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1); load_b(bnext, 1, t + 1));
+        SB(); MF(5, 1); A2(load_b(bnext, 2, t + 1); load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
+        SB(); MF(0, 2); A8(cTA());
+        SB(); MF(5, 2); A8(rdB(par ^ 1));
+        SB(); MF(0, 3); A1(store_raw(rset[par], par));
+        SB(); MF(5, 3); A1(load_raw(rset[par], t + 4));
+        SB(); MF(1, 0); A8(cTB());
+        SB(); MF(2, 0); A8(cV05());
         SB(); MF(1, 1);
         SB(); MF(2, 1);
         SB(); MF(1, 2);
         SB(); MF(2, 2);
         SB(); MF(1, 3);
         SB(); MF(2, 3);
-        SB(); MF(3, 0); cV12();
-        SB(); MF(4, 0); load_b(1, t + 1); load_b(2, t + 1);
+        SB(); MF(3, 0); A8(cV12());
+        SB(); MF(4, 0);
         SB(); MF(3, 1);
         SB(); MF(4, 1);
         SB(); MF(3, 2);
         SB(); MF(4, 2);
         SB(); MF(3, 3);
-        SB(); MF(4, 3); load_b(3, t + 1); load_b(4, t + 1);
+        SB(); MF(4, 3);
         SB();
-        __syncthreads();
+        if (!(SEAM_W24_ABL & 4)) __syncthreads();
     };
     for (int t = 0; t < p.nchunks; t += 2) {
-        chunk(t, 0);
-        if (t + 1 < p.nchunks) chunk(t + 1, 1);
+        chunk(t, 0, bfs[0], bfs[1]);
+        if (t + 1 < p.nchunks) chunk(t + 1, 1, bfs[1], bfs[0]);
     }
 #undef SB
 #undef MF
+#undef A1
+#undef A2
+#undef A8
 
     // ---- epilogue: output transform + scale/shift (+ residual, ReLU) ------------------------------------------------
     //   columns (A4t over nu): Y0 = m0+m1+m2+m3+m4, Y1 = (m1-m2) + 2(m3-m4), Y2 = (m1+m2) + 4(m3+m4), Y3 = (m1-m2) + 8(m3-m4) + m5
@@ -454,7 +484,7 @@ struct Layout {
 constexpr int CAP = 32;
 
 inline bool patch_ok(int tx, int ty) {
-    return tx >= 1 && ty >= 1 && tx * ty <= CAP && (4 * tx + 2) * (2 * ty + 2) <= NPIXMAX && 4 * (tx + 1) * (2 * ty + 2) <= ENTMAX;
+    return tx >= 1 && ty >= 1 && tx * ty <= CAP && (4 * tx + 2) * (2 * ty + 2) <= NPIXMAX && (8 * (tx + 1) + (tx & 7)) * (ty + 1) <= ENTMAX;
 }
 
 inline long best_uniform(int w, int h, int& TX, int& TY) {
@@ -486,7 +516,7 @@ inline Layout choose_layout(int N, int tiles_x, int tiles_y, size_t in_img_bytes
                 if (span > phmax) phmax = span;
                 if (gl + 1 > gmax) gmax = gl + 1;
             }
-            if (phmax * pw > NPIXMAX || 4 * (tiles_x + 1) * phmax > ENTMAX) continue;
+            if (phmax * pw > NPIXMAX || (8 * (tiles_x + 1) + (tiles_x & 7)) * ((phmax + 1) / 2) > ENTMAX) continue;
             if ((size_t)gmax * in_img_bytes >= kOob || (size_t)gmax * out_img_bytes >= kOob) continue;
             S.nreg = 1; S.stack = 1; S.PH = phmax; S.G = gmax;
             S.rx0[0] = S.ry0[0] = 0; S.rxe[0] = tiles_x; S.rye[0] = tiles_y; S.TX[0] = tiles_x; S.TY[0] = ty; S.bx[0] = S.by[0] = 1;

@@ -97,10 +97,12 @@ _WINO24 = {}
 def _wino24_pays(lib, n, h, w, c, k, pad) -> bool:
     if WINOGRAD24 >= 2:
         return True
-    key = (n, h, w, c, k, pad)
+    # decided on the map geometry alone (a canonical batch of 256 images): an image's result must not depend on the batch it
+    # rides in (the two forms round differently), and the stacked layouts of small maps would make the ratio vary with n
+    key = (h, w, c, k, pad)
     f = _WINO24.get(key)
     if f is None:
-        s24, s22 = int(lib.seam_wino24_issue_slots(n, h, w, c, k, pad)), int(lib.seam_wino_issue_slots(n, h, w, c, k, pad))
+        s24, s22 = int(lib.seam_wino24_issue_slots(256, h, w, c, k, pad)), int(lib.seam_wino_issue_slots(256, h, w, c, k, pad))
         f = _WINO24[key] = s24 > 0 and s24 <= WINO24_MARGIN * s22
     return f
 
