@@ -114,12 +114,14 @@ struct Wino24Args {
 
 constexpr int NPIXMAX = 384;                       // raw patch pixels per buffer (3 x 16-byte loads per thread per chunk)
 constexpr int NI = (2 * NPIXMAX + 255) / 256;
-constexpr int ENTMAX = 448;                        // 16-byte LDS entries per channel half (row pairs x PR, see the kernel)
+constexpr int ENTMAX = 672;                        // 16-byte LDS entries per channel half (row pairs x PR, see the kernel)
 constexpr int RAWB = (2 * ENTMAX + 1) * 16;        // bytes per raw buffer (+1 dump slot for idle loader lanes)
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
+    // two raw patch buffers; the epilogue's exchange array ex[xi][b][tile][n] (32 KiB) reuses the same memory after the K loop
+    static_assert(2 * RAWB >= 4 * 2 * 32 * 32 * 4, "exchange array must fit in the raw buffers");
     __shared__ __attribute__((aligned(16))) char raw[2][RAWB];
-    __shared__ __attribute__((aligned(16))) float ex[4 * 2 * 32 * 32];      // epilogue exchange [xi][b][tile][n]
+    float* const ex = reinterpret_cast<float*>(&raw[0][0]);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,12 +157,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
 
     const int PW = 4 * TX + 2, PH = p.stack ? p.PH : 2 * TY + 2;
     const int NPIX = PW * PH;
-    const int HS = TX + 1;                                 // 16-byte entries per (patch row, x mod 4)
+    const int HS = (TX + 1) | 1;                           // 16-byte entries per (patch row, x mod 4); odd: the four x phases of
+                                                           // consecutive pixels land in four different 16-byte bank groups (stores)
     // A pair of patch rows (= one tile row step) takes PR entries, PR = 8 * HS rounded up to TX (mod 8): tile (r, tx) then
     // sits at r * PR + tx = lane (mod 8) -- the eight lanes of a ds_read_b128 phase always hit eight different 16-byte
     // bank groups, whatever the patch shape (without it tile rows alias: 8 * HS = 0 mod 8, two-way conflicts for TX < 8)
     const int PR = 8 * HS + (TX & 7);
-    const int NENT = PR * ((PH + 1) >> 1);                 // entries per channel half
+    const int NENT0 = PR * ((PH + 1) >> 1);                // entries per channel half ...
+    const int NENT = NENT0 + ((4 - NENT0) & 7);            // ... placed 4 (mod 8) apart: the two halves of a pixel (adjacent loader
+                                                           // lanes) never share a bank group
     const int nslots = TX * TY;
     auto slot = [&](int id, int& g, int& ty, int& tx, int& prow) -> bool {
         const int r = id / TX;
@@ -483,8 +488,14 @@ struct Layout {
 
 constexpr int CAP = 32;
 
+// LDS entries per channel half for a patch of tx tiles x ph rows (the kernel's HS / PR / NENT)
+inline int lds_entries(int tx, int ph) {
+    const int hs = (tx + 1) | 1, pr = 8 * hs + (tx & 7), n0 = pr * ((ph + 1) / 2);
+    return n0 + ((4 - n0) & 7);
+}
+
 inline bool patch_ok(int tx, int ty) {
-    return tx >= 1 && ty >= 1 && tx * ty <= CAP && (4 * tx + 2) * (2 * ty + 2) <= NPIXMAX && (8 * (tx + 1) + (tx & 7)) * (ty + 1) <= ENTMAX;
+    return tx >= 1 && ty >= 1 && tx * ty <= CAP && (4 * tx + 2) * (2 * ty + 2) <= NPIXMAX && lds_entries(tx, 2 * ty + 2) <= ENTMAX;
 }
 
 inline long best_uniform(int w, int h, int& TX, int& TY) {
@@ -516,7 +527,7 @@ inline Layout choose_layout(int N, int tiles_x, int tiles_y, size_t in_img_bytes
                 if (span > phmax) phmax = span;
                 if (gl + 1 > gmax) gmax = gl + 1;
             }
-            if (phmax * pw > NPIXMAX || (8 * (tiles_x + 1) + (tiles_x & 7)) * ((phmax + 1) / 2) > ENTMAX) continue;
+            if (phmax * pw > NPIXMAX || lds_entries(tiles_x, phmax) > ENTMAX) continue;
             if ((size_t)gmax * in_img_bytes >= kOob || (size_t)gmax * out_img_bytes >= kOob) continue;
             S.nreg = 1; S.stack = 1; S.PH = phmax; S.G = gmax;
             S.rx0[0] = S.ry0[0] = 0; S.rxe[0] = tiles_x; S.rye[0] = tiles_y; S.TX[0] = tiles_x; S.TY[0] = ty; S.bx[0] = S.by[0] = 1;

@@ -90,7 +90,7 @@ def _pack_wino24(lib, weight: torch.Tensor, K: int, cin: int, cs: int, mode: int
 
 # F(2x4,3x3) (csrc/seam_wino24.hip): 0 = never, 1 = where it issues fewer MFMAs than F(2x2,3x3) (x WINO24_MARGIN), 2 = always
 WINOGRAD24 = int(_os.environ.get("SEAM_WINOGRAD24", "1"))
-WINO24_MARGIN = float(_os.environ.get("SEAM_WINO24_MARGIN", "0.85"))
+WINO24_MARGIN = float(_os.environ.get("SEAM_WINO24_MARGIN", "0.95"))
 _WINO24 = {}
 
 

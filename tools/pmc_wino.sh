@@ -10,7 +10,7 @@ rows=list(csv.DictReader(open("/tmp/pmcw/p_counter_collection.csv")))
 agg=collections.defaultdict(lambda: collections.defaultdict(list)); dur=collections.defaultdict(list)
 for r in rows:
     n=r["Kernel_Name"]
-    k="igemm" if "conv_igemm" in n else "wino" if "conv3x3_wino" in n else None
+    k="igemm" if "conv_igemm" in n else "wino24" if "conv3x3_wino24" in n else "wino" if "conv3x3_wino" in n else None
     if k:
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"])); dur[k].append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
 for k in agg:
