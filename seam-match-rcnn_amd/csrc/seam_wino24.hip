@@ -81,6 +81,12 @@ __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+#ifndef SEAM_W24_AGPR
+#define SEAM_W24_AGPR 0     // 1: accumulators in AccVGPRs (measured: 1-2 % slower than the VGPR form hipcc picks by itself)
+#endif
+#ifndef SEAM_W24_SCHED
+#define SEAM_W24_SCHED 2    // K-loop schedule variants (all within 1 % of each other: the loop is not latency-bound)
+#endif
 #ifndef SEAM_W24_ABL
 #define SEAM_W24_ABL 0      // kernel experiments (tools/experiments/wino24_abl.sh; operands keep the REAL data of chunks 0/1):
                             // 1 no in-loop patch loads / LDS stores, 2 no in-loop weight loads, 4 no barrier, 8 no in-loop transforms
@@ -110,7 +116,13 @@ struct Wino24Args {
     int G;
     int tiles_n;          // K / 32
     int nchunks;          // C / 8
+    // ceil(2^32 / d) of the divisors the block prologue needs (fdiv below): an integer division costs ~20 VALU instructions,
+    // and VALU instructions of either resident block delay the matrix pipe
+    unsigned m_tiles_n, m_per_img, m_tys, m_pitch, m_bx[3], m_TX[3], m_PW[3];
 };
+
+// a / d for 0 <= a, a * d < 2^32, with m = ceil(2^32 / d) (d >= 2) -- one v_mul_hi_u32 / s_mul_hi_u32
+__device__ __forceinline__ int fdiv(int a, int d, unsigned m) { return d == 1 ? a : (int)__umulhi((unsigned)a, m); }
 
 constexpr int NPIXMAX = 384;                       // raw patch pixels per buffer (3 x 16-byte loads per thread per chunk)
 constexpr int NI = (2 * NPIXMAX + 255) / 256;
@@ -133,10 +145,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     const int xcd = b & 7;
     const int q8 = nblk >> 3, rem8 = nblk & 7;
     const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
-    const int tm = tile / p.tiles_n;
+    const int tm = fdiv(tile, p.tiles_n, p.m_tiles_n);
     const int tn = tile - tm * p.tiles_n;
     const int per_img = p.per_img;
-    int rb = tm - (tm / per_img) * per_img;
+    const int tm_img = fdiv(tm, per_img, p.m_per_img);
+    int rb = tm - tm_img * per_img;
     int reg = 0;
     if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
         rb -= p.bx[0] * p.by[0];
@@ -144,11 +157,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
     }
     const int TX = p.TX[reg], TY = p.TY[reg];
-    const int byi = rb / p.bx[reg];
+    const int byi = fdiv(rb, p.bx[reg], p.m_bx[reg]);
     const int bxi = rb - byi * p.bx[reg];
     const int tys = p.tiles_y, pitch = 2 * tys + 2;
     const int R0 = tm * TY;                                // stacked mode: first tile row (global) of this block
-    const int n_img = p.stack ? R0 / tys : tm / per_img;   // first image of this block
+    const int n_img = p.stack ? fdiv(R0, tys, p.m_tys) : tm_img;   // first image of this block
     const int prow0 = p.stack ? 2 * (R0 - n_img * tys) : 0;
     const int n_here = min(p.G, p.N - n_img);
     const int ty0 = p.stack ? 0 : p.ry0[reg] + byi * TY, tx0 = p.stack ? 0 : p.rx0[reg] + bxi * TX;
@@ -168,11 +181,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
                                                            // lanes) never share a bank group
     const int nslots = TX * TY;
     auto slot = [&](int id, int& g, int& ty, int& tx, int& prow) -> bool {
-        const int r = id / TX;
+        const int r = fdiv(id, TX, p.m_TX[reg]);
         tx = tx0 + (id - r * TX);
         if (p.stack) {
             const int R = R0 + r;
-            const int n = R / tys;
+            const int n = fdiv(R, tys, p.m_tys);
             g = n - n_img;
             ty = R - n * tys;
             prow = pitch * g + 2 * ty - prow0;
@@ -196,12 +209,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         const int half = idx & 1;
         const int pix = idx >> 1;
         const bool ok = pix < NPIX;
-        const int v = pix / PW;                            // patch row
+        const int v = fdiv(pix, PW, p.m_PW[reg]);          // patch row
         const int px = pix - v * PW;
         int g = 0, gy = iy0 + v;
         if (p.stack) {
             const int vr = prow0 + v;
-            g = vr / pitch;
+            g = fdiv(vr, pitch, p.m_pitch);
             gy = vr - g * pitch - p.pad;
         }
         const int gx = ix0 + px;
@@ -294,6 +307,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     for (int nu = 0; nu < 6; ++nu)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+#if SEAM_W24_AGPR
+    // An "a" constraint anywhere in the kernel makes hipcc keep the MFMA accumulators in the AccVGPR half of the register file
+    // (without it the function is marked amdgpu-no-agpr and the VGPR form is selected): the C/D traffic of the matrix pipe
+    // then no longer shares register ports with the transform's VALU instructions.
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) asm volatile("" : "+a"(acc[nu]));
+#endif
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define MF(nu, kk) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[nu][kk], bcur[nu][kk], acc[nu], 0, 0, 0)
@@ -321,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     // vector-memory counter retires in order, so a wait for a weight fragment also waits for every older load: with the
     // weights first, the (HBM-latency) patch loads of chunk t are not forced to complete before the top of chunk t+2.
     auto chunk = [&](int t, int par, f32x4 (&bcur)[6], f32x4 (&bnext)[6]) {
+#if SEAM_W24_SCHED == 0
         SB(); MF(0, 0); A8(cV34());
         SB(); MF(5, 0); A8(rdA(par ^ 1));
         SB(); MF(0, 1); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1); load_b(bnext, 1, t + 1));
@@ -346,6 +367,85 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         SB(); MF(3, 3);
         SB(); MF(4, 3);
         SB();
+#elif SEAM_W24_SCHED == 1      // more distance between the LDS reads and their first use
+        SB(); MF(0, 0); A8(cV34()); A8(rdA(par ^ 1));
+        SB(); MF(5, 0); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1); load_b(bnext, 1, t + 1));
+        SB(); MF(0, 1); A2(load_b(bnext, 2, t + 1); load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
+        SB(); MF(5, 1);
+        SB(); MF(0, 2); A8(cTA());
+        SB(); MF(5, 2); A8(rdB(par ^ 1));
+        SB(); MF(0, 3); A1(store_raw(rset[par], par));
+        SB(); MF(5, 3); A1(load_raw(rset[par], t + 4));
+        SB(); MF(1, 0);
+        SB(); MF(2, 0); A8(cTB());
+        SB(); MF(1, 1); A8(cV05());
+        SB(); MF(2, 1);
+        SB(); MF(1, 2);
+        SB(); MF(2, 2);
+        SB(); MF(1, 3);
+        SB(); MF(2, 3);
+        SB(); MF(3, 0); A8(cV12());
+        SB(); MF(4, 0);
+        SB(); MF(3, 1);
+        SB(); MF(4, 1);
+        SB(); MF(3, 2);
+        SB(); MF(4, 2);
+        SB(); MF(3, 3);
+        SB(); MF(4, 3);
+        SB();
+#elif SEAM_W24_SCHED == 2      // patch store / load late in the chunk, weights in the middle
+        SB(); MF(0, 0); A8(cV34());
+        SB(); MF(5, 0); A8(rdA(par ^ 1));
+        SB(); MF(0, 1);
+        SB(); MF(5, 1);
+        SB(); MF(0, 2); A8(cTA());
+        SB(); MF(5, 2); A8(rdB(par ^ 1));
+        SB(); MF(0, 3);
+        SB(); MF(5, 3);
+        SB(); MF(1, 0); A8(cTB());
+        SB(); MF(2, 0); A8(cV05());
+        SB(); MF(1, 1); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1); load_b(bnext, 1, t + 1));
+        SB(); MF(2, 1); A2(load_b(bnext, 2, t + 1); load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
+        SB(); MF(1, 2);
+        SB(); MF(2, 2);
+        SB(); MF(1, 3);
+        SB(); MF(2, 3);
+        SB(); MF(3, 0); A8(cV12());
+        SB(); MF(4, 0); A1(store_raw(rset[par], par));
+        SB(); MF(3, 1); A1(load_raw(rset[par], t + 4));
+        SB(); MF(4, 1);
+        SB(); MF(3, 2);
+        SB(); MF(4, 2);
+        SB(); MF(3, 3);
+        SB(); MF(4, 3);
+        SB();
+#else                          // pieces spread thinly: at most one kind of work per slot, idle slots in between
+        SB(); MF(0, 0); A8(cV34());
+        SB(); MF(5, 0); A8(rdA(par ^ 1));
+        SB(); MF(0, 1); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1));
+        SB(); MF(5, 1); A2(load_b(bnext, 1, t + 1); load_b(bnext, 2, t + 1));
+        SB(); MF(0, 2); A8(cTA());
+        SB(); MF(5, 2); A8(rdB(par ^ 1));
+        SB(); MF(0, 3); A2(load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
+        SB(); MF(5, 3);
+        SB(); MF(1, 0); A8(cTB());
+        SB(); MF(2, 0);
+        SB(); MF(1, 1); A8(cV05());
+        SB(); MF(2, 1);
+        SB(); MF(1, 2); A1(store_raw(rset[par], par));
+        SB(); MF(2, 2);
+        SB(); MF(1, 3); A1(load_raw(rset[par], t + 4));
+        SB(); MF(2, 3);
+        SB(); MF(3, 0); A8(cV12());
+        SB(); MF(4, 0);
+        SB(); MF(3, 1);
+        SB(); MF(4, 1);
+        SB(); MF(3, 2);
+        SB(); MF(4, 2);
+        SB(); MF(3, 3);
+        SB(); MF(4, 3);
+        SB();
+#endif
         if (!(SEAM_W24_ABL & 4)) __syncthreads();
     };
     for (int t = 0; t < p.nchunks; t += 2) {
@@ -375,23 +475,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     int g, tyt, txt, prow_unused;
     const bool tile_ok = slot(et, g, tyt, txt, prow_unused) && g < n_here;
     const int oy = 2 * tyt, ox = 4 * txt;
+    const int cstep = p.K * 4, rstep = p.Wo * cstep;                      // bytes per output pixel / row
+    const unsigned obase = (unsigned)(((g * p.Ho + oy) * p.Wo + ox) * p.K + ncol) * 4u;
+    // nu half (A4t) on register PAIRS (acc[nu][r], acc[nu][r+1] are adjacent VGPRs): packed fp32, half the VALU instructions
+    f32x2 yy[4][8];
+    {
+        const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const f32x2 m0 = {acc[0][2 * h], acc[0][2 * h + 1]}, m1 = {acc[1][2 * h], acc[1][2 * h + 1]};
+            const f32x2 m2 = {acc[2][2 * h], acc[2][2 * h + 1]}, m3 = {acc[3][2 * h], acc[3][2 * h + 1]};
+            const f32x2 m4 = {acc[4][2 * h], acc[4][2 * h + 1]}, m5 = {acc[5][2 * h], acc[5][2 * h + 1]};
+            const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
+            yy[0][h] = pk_add(pk_add(m0, s12), s34);
+            yy[1][h] = pk_fma_s(c2, d34, d12);
+            yy[2][h] = pk_fma_s(c4, s34, s12);
+            yy[3][h] = pk_add(pk_fma_s(c8, d34, d12), m5);
+        }
+    }
 #pragma unroll
     for (int bp = 0; bp < 2; ++bp) {
-        __syncthreads();              // previous readers of `ex` are done
+        __syncthreads();              // previous readers of `ex` (first pass: of the raw buffers it aliases) are done
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int h = 0; h < 8; ++h) {
+            const int r = 2 * h;
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r];
-            float ya, yb;
-            if (bp == 0) {
-                ya = acc[0][r] + (m1 + m2) + (m3 + m4);
-                yb = (m1 - m2) + 2.f * (m3 - m4);
-            } else {
-                ya = (m1 + m2) + 4.f * (m3 + m4);
-                yb = (m1 - m2) + 8.f * (m3 - m4) + acc[5][r];
-            }
-            ex[((xi * 2 + 0) * 32 + row) * 32 + (lane & 31)] = ya;
-            ex[((xi * 2 + 1) * 32 + row) * 32 + (lane & 31)] = yb;
+            float* e0 = &ex[((xi * 2 + 0) * 32 + row) * 32 + (lane & 31)];
+            e0[0] = yy[2 * bp][h][0];
+            e0[32] = yy[2 * bp][h][1];
+            e0[32 * 32] = yy[2 * bp + 1][h][0];
+            e0[32 * 32 + 32] = yy[2 * bp + 1][h][1];
         }
         __syncthreads();
 #pragma unroll
@@ -403,11 +516,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
             f32x4 yv[2];
             yv[0] = q0 + q1 + q2;
             yv[1] = q1 - q2 - q3;
-            const int oxx = ox + 2 * bp + bb;
+            const int bcol = 2 * bp + bb;
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) {
-                const bool ok = tile_ok && (oy + aa) < p.Ho && oxx < p.Wo;
-                const unsigned off = ok ? (unsigned)(((((g * p.Ho + oy + aa) * p.Wo) + oxx) * p.K + ncol) * 4) : kOob;
+                const bool ok = tile_ok && (oy + aa) < p.Ho && (ox + bcol) < p.Wo;
+                const unsigned off = ok ? obase + (unsigned)(aa * rstep + bcol * cstep) : kOob;
                 f32x4 v = yv[aa] * sc + sh;
                 if (p.res) {
                     const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
@@ -595,7 +708,10 @@ int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long&
         a.TX[r] = pp.TX[q]; a.TY[r] = pp.TY[q]; a.bx[r] = pp.bx[q]; a.by[r] = pp.by[q];
     }
     blocks = pp.blocks * a.tiles_n;
-    if (blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    if (blocks >= (1L << 24)) return (int)hipErrorInvalidValue;     // also keeps every fdiv operand inside a * d < 2^32
+    auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+    a.m_tiles_n = magic(a.tiles_n); a.m_per_img = magic(a.per_img); a.m_tys = magic(tiles_y); a.m_pitch = magic(2 * tiles_y + 2);
+    for (int r = 0; r < 3; ++r) { a.m_bx[r] = magic(a.bx[r]); a.m_TX[r] = magic(a.TX[r]); a.m_PW[r] = magic(4 * a.TX[r] + 2); }
     return 0;
 }
 

@@ -34,9 +34,10 @@ def test_bench_line_and_roofline_fields():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] > 0.3
     if r["kernel"].startswith("conv3x3_wino"):
-        # `achieved` counts ALGORITHMIC FLOPs (2*M*K*9*C); Winograd F(2x2,3x3) issues 2.25x fewer, so frac may pass 1.0
-        # while the issued-MFMA fraction stays below the peak
-        assert abs(r["mfma_issued_frac"] - r["frac"] / 2.25) < 1e-3 and r["mfma_issued_frac"] < 1.0
+        # `achieved` counts ALGORITHMIC FLOPs (2*M*K*9*C); Winograd F(2x2,3x3) issues 2.25x fewer MFMAs and F(2x4,3x3) 3x
+        # fewer, so frac may pass 1.0 while the issued-MFMA fraction stays below the peak
+        red = 3.0 if r["kernel"] == "conv3x3_wino24" else 2.25
+        assert abs(r["mfma_issued_frac"] - r["frac"] / red) < 1e-3 and r["mfma_issued_frac"] < 1.0
     else:
         assert r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 0
