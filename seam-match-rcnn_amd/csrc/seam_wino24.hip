@@ -81,12 +81,6 @@ __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-#ifndef SEAM_W24_AGPR
-#define SEAM_W24_AGPR 0     // 1: accumulators in AccVGPRs (measured: 1-2 % slower than the VGPR form hipcc picks by itself)
-#endif
-#ifndef SEAM_W24_SCHED
-#define SEAM_W24_SCHED 2    // K-loop schedule variants (all within 1 % of each other: the loop is not latency-bound)
-#endif
 #ifndef SEAM_W24_ABL
 #define SEAM_W24_ABL 0      // kernel experiments (tools/experiments/wino24_abl.sh; operands keep the REAL data of chunks 0/1):
                             // 1 no in-loop patch loads / LDS stores, 2 no in-loop weight loads, 4 no barrier, 8 no in-loop transforms
@@ -114,7 +108,7 @@ struct Wino24Args {
     int tiles_y;
     int PH;
     int G;
-    int tiles_n;          // K / 32
+    int tiles_n;          // K / (32 * NT)
     int nchunks;          // C / 8
     // ceil(2^32 / d) of the divisors the block prologue needs (fdiv below): an integer division costs ~20 VALU instructions,
     // and VALU instructions of either resident block delay the matrix pipe
@@ -129,11 +123,20 @@ constexpr int NI = (2 * NPIXMAX + 255) / 256;
 constexpr int ENTMAX = 672;                        // 16-byte LDS entries per channel half (row pairs x PR, see the kernel)
 constexpr int RAWB = (2 * ENTMAX + 1) * 16;        // bytes per raw buffer (+1 dump slot for idle loader lanes)
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
-    // two raw patch buffers; the epilogue's exchange array ex[xi][b][tile][n] (32 KiB) reuses the same memory after the K loop
-    static_assert(2 * RAWB >= 4 * 2 * 32 * 32 * 4, "exchange array must fit in the raw buffers");
-    __shared__ __attribute__((aligned(16))) char raw[2][RAWB];
-    float* const ex = reinterpret_cast<float*>(&raw[0][0]);
+// NT = 32-channel n-tiles per block.  NT = 1: 96 accumulator VGPRs, two blocks per CU.  NT = 2: 192 accumulators (AccVGPRs), one block
+// per CU, one wave per SIMD: every A fragment (the transform's output) and the raw patch feed twice the MFMAs.  Measured on this
+// kernel: a SIMD does not overlap its MFMAs with anything else it issues -- one resident block instead of two costs only 10 %,
+// MFMAs-only runs at the same speed with one or two blocks, and the K loop's time is the sum of its MFMA cycles and ~16 cycles per
+// other vector instruction -- so what counts is MFMAs per transform / LDS / load instruction, not occupancy.
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Wino24Args p) {
+    // two raw patch buffers; the epilogue's exchange array ex[xi][b][tile][n] (64 KiB, all four output columns of a tile in one
+    // pass) reuses the same memory after the K loop
+    constexpr int EXB = 4 * 4 * 32 * 32 * 4;
+    static_assert(2 * RAWB <= EXB, "the raw buffers live inside the exchange array's 64 KiB");
+    __shared__ __attribute__((aligned(16))) char smem[EXB];
+    char (*raw)[RAWB] = reinterpret_cast<char (*)[RAWB]>(smem);
+    float* const ex = reinterpret_cast<float*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         loff[i] = ok ? (half * NENT + (v >> 1) * PR + ((v & 1) * 4 + (px & 3)) * HS + (px >> 2)) * 16 : 2 * ENTMAX * 16;
     }
     const int last_chunk = p.nchunks - 1;
-    f32x4 rset[2][NI];
+    constexpr int NRS = NT == 1 ? 2 : 1;     // register sets of the raw patch: prefetch distance 2 chunks / 1 (twice as long) chunk
+    f32x4 rset[NRS][NI];
     auto load_raw = [&](f32x4 (&rs)[NI], int chunk) {
         const int c = chunk < last_chunk ? chunk : last_chunk;     // past the end: re-read the last chunk (never used)
 #pragma unroll
@@ -235,14 +239,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(&raw[buf][loff[i]]) = rs[i];
     };
 
-    // ---- weight fragments: [tn][chunk][p = 6*xi + nu][lane][4] ----------------------------------------------------
+    // ---- weight fragments: [tn32][chunk][p = 6*xi + nu][lane][4]; this block's n-tiles are tn32 = NT * tn + nt --------
+    const int ntile_bytes = p.nchunks * 24576;
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.u + (size_t)tn * p.nchunks * 24576), 0, p.nchunks * 24576, 0x00020000);
-    const int uoff = (xi * 6 * 64 + lane) * 16;
-    f32x4 bfs[2][6];
-    auto load_b = [&](f32x4 (&bf)[6], int nu, int chunk) {
+        (void*)((const char*)p.u + (size_t)tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
+    const int uoff[1] = {(xi * 6 * 64 + lane) * 16};
+    constexpr int NBS = NT == 1 ? 2 : 1;     // weight register sets: NT = 2 keeps ONE that rolls (arch VGPRs are the limit there)
+    f32x4 bfs[NBS][NT][6];
+    auto load_b = [&](f32x4 (&bf)[NT][6], int nu, int chunk) {       // position nu of every n-tile
         const int c = chunk < last_chunk ? chunk : last_chunk;
-        bf[nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff + nu * 1024, c * 24576, 0));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            bf[nt][nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff[0], c * 24576 + nu * 1024 + nt * ntile_bytes, 0));   // one lane offset; the rest is scalar
     };
 
     // ---- input transform --------------------------------------------------------------------------------------------
@@ -302,31 +310,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         va[4] = fma4s(km2, d, c);
     };
 
-    f32x16 acc[6];
+    f32x16 acc[6][NT];
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
-#if SEAM_W24_AGPR
-    // An "a" constraint anywhere in the kernel makes hipcc keep the MFMA accumulators in the AccVGPR half of the register file
-    // (without it the function is marked amdgpu-no-agpr and the VGPR form is selected): the C/D traffic of the matrix pipe
-    // then no longer shares register ports with the transform's VALU instructions.
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu) asm volatile("" : "+a"(acc[nu]));
-#endif
+            for (int r = 0; r < 16; ++r) acc[nu][nt][r] = 0.f;
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
-#define MF(nu, kk) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[nu][kk], bcur[nu][kk], acc[nu], 0, 0, 0)
+#define MF(nu, kk) do { _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { \
+        acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[nu][kk], bcur[nt][nu][kk], acc[nu][nt], 0, 0, 0); if (nt + 1 < NT) SB(); } } while (0)
 
     // ---- prologue -------------------------------------------------------------------------------------------------
     load_raw(rset[0], 0);
-    load_raw(rset[1], 1);
+    if constexpr (NRS == 2) load_raw(rset[1], 1);
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu) load_b(bfs[0], nu, 0);
     store_raw(rset[0], 0);
-    store_raw(rset[1], 1);
-    load_raw(rset[0], 2);
-    load_raw(rset[1], 3);
+    if constexpr (NRS == 2) {
+        store_raw(rset[1], 1);
+        load_raw(rset[0], 2);
+        load_raw(rset[1], 3);
+    } else {
+        load_raw(rset[0], 1);
+        store_raw(rset[0], 1);
+        load_raw(rset[0], 2);
+    }
     __syncthreads();
     rdA(0); cTA(); rdB(0); cTB(); cV05(); cV12();     // V3, V4 of chunk 0 are made in its first slot
     __syncthreads();                                  // chunk 0 overwrites raw[0] right away
@@ -340,117 +350,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
     // Weights: two register sets, all six loads of chunk t+1 issued at the top of chunk t, BEFORE the patch loads -- the
     // vector-memory counter retires in order, so a wait for a weight fragment also waits for every older load: with the
     // weights first, the (HBM-latency) patch loads of chunk t are not forced to complete before the top of chunk t+2.
-    auto chunk = [&](int t, int par, f32x4 (&bcur)[6], f32x4 (&bnext)[6]) {
-#if SEAM_W24_SCHED == 0
-        SB(); MF(0, 0); A8(cV34());
-        SB(); MF(5, 0); A8(rdA(par ^ 1));
-        SB(); MF(0, 1); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1); load_b(bnext, 1, t + 1));
-        SB(); MF(5, 1); A2(load_b(bnext, 2, t + 1); load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
-        SB(); MF(0, 2); A8(cTA());
-        SB(); MF(5, 2); A8(rdB(par ^ 1));
-        SB(); MF(0, 3); A1(store_raw(rset[par], par));
-        SB(); MF(5, 3); A1(load_raw(rset[par], t + 4));
-        SB(); MF(1, 0); A8(cTB());
-        SB(); MF(2, 0); A8(cV05());
-        SB(); MF(1, 1);
-        SB(); MF(2, 1);
-        SB(); MF(1, 2);
-        SB(); MF(2, 2);
-        SB(); MF(1, 3);
-        SB(); MF(2, 3);
-        SB(); MF(3, 0); A8(cV12());
-        SB(); MF(4, 0);
-        SB(); MF(3, 1);
-        SB(); MF(4, 1);
-        SB(); MF(3, 2);
-        SB(); MF(4, 2);
-        SB(); MF(3, 3);
-        SB(); MF(4, 3);
-        SB();
-#elif SEAM_W24_SCHED == 1      // more distance between the LDS reads and their first use
-        SB(); MF(0, 0); A8(cV34()); A8(rdA(par ^ 1));
-        SB(); MF(5, 0); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1); load_b(bnext, 1, t + 1));
-        SB(); MF(0, 1); A2(load_b(bnext, 2, t + 1); load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
-        SB(); MF(5, 1);
-        SB(); MF(0, 2); A8(cTA());
-        SB(); MF(5, 2); A8(rdB(par ^ 1));
-        SB(); MF(0, 3); A1(store_raw(rset[par], par));
-        SB(); MF(5, 3); A1(load_raw(rset[par], t + 4));
-        SB(); MF(1, 0);
-        SB(); MF(2, 0); A8(cTB());
-        SB(); MF(1, 1); A8(cV05());
-        SB(); MF(2, 1);
-        SB(); MF(1, 2);
-        SB(); MF(2, 2);
-        SB(); MF(1, 3);
-        SB(); MF(2, 3);
-        SB(); MF(3, 0); A8(cV12());
-        SB(); MF(4, 0);
-        SB(); MF(3, 1);
-        SB(); MF(4, 1);
-        SB(); MF(3, 2);
-        SB(); MF(4, 2);
-        SB(); MF(3, 3);
-        SB(); MF(4, 3);
-        SB();
-#elif SEAM_W24_SCHED == 2      // patch store / load late in the chunk, weights in the middle
-        SB(); MF(0, 0); A8(cV34());
-        SB(); MF(5, 0); A8(rdA(par ^ 1));
-        SB(); MF(0, 1);
-        SB(); MF(5, 1);
-        SB(); MF(0, 2); A8(cTA());
-        SB(); MF(5, 2); A8(rdB(par ^ 1));
-        SB(); MF(0, 3);
-        SB(); MF(5, 3);
-        SB(); MF(1, 0); A8(cTB());
-        SB(); MF(2, 0); A8(cV05());
-        SB(); MF(1, 1); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1); load_b(bnext, 1, t + 1));
-        SB(); MF(2, 1); A2(load_b(bnext, 2, t + 1); load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
-        SB(); MF(1, 2);
-        SB(); MF(2, 2);
-        SB(); MF(1, 3);
-        SB(); MF(2, 3);
-        SB(); MF(3, 0); A8(cV12());
-        SB(); MF(4, 0); A1(store_raw(rset[par], par));
-        SB(); MF(3, 1); A1(load_raw(rset[par], t + 4));
-        SB(); MF(4, 1);
-        SB(); MF(3, 2);
-        SB(); MF(4, 2);
-        SB(); MF(3, 3);
-        SB(); MF(4, 3);
-        SB();
-#else                          // pieces spread thinly: at most one kind of work per slot, idle slots in between
-        SB(); MF(0, 0); A8(cV34());
-        SB(); MF(5, 0); A8(rdA(par ^ 1));
-        SB(); MF(0, 1); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1));
-        SB(); MF(5, 1); A2(load_b(bnext, 1, t + 1); load_b(bnext, 2, t + 1));
-        SB(); MF(0, 2); A8(cTA());
-        SB(); MF(5, 2); A8(rdB(par ^ 1));
-        SB(); MF(0, 3); A2(load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
-        SB(); MF(5, 3);
-        SB(); MF(1, 0); A8(cTB());
-        SB(); MF(2, 0);
-        SB(); MF(1, 1); A8(cV05());
-        SB(); MF(2, 1);
-        SB(); MF(1, 2); A1(store_raw(rset[par], par));
-        SB(); MF(2, 2);
-        SB(); MF(1, 3); A1(load_raw(rset[par], t + 4));
-        SB(); MF(2, 3);
-        SB(); MF(3, 0); A8(cV12());
-        SB(); MF(4, 0);
-        SB(); MF(3, 1);
-        SB(); MF(4, 1);
-        SB(); MF(3, 2);
-        SB(); MF(4, 2);
-        SB(); MF(3, 3);
-        SB(); MF(4, 3);
-        SB();
-#endif
+    auto chunk = [&](int t, int par, f32x4 (&bcur)[NT][6], f32x4 (&bnext)[NT][6]) {
+        if constexpr (NT == 1) {
+            SB(); MF(0, 0); A8(cV34());
+            SB(); MF(5, 0); A8(rdA(par ^ 1));
+            SB(); MF(0, 1);
+            SB(); MF(5, 1);
+            SB(); MF(0, 2); A8(cTA());
+            SB(); MF(5, 2); A8(rdB(par ^ 1));
+            SB(); MF(0, 3);
+            SB(); MF(5, 3);
+            SB(); MF(1, 0); A8(cTB());
+            SB(); MF(2, 0); A8(cV05());
+            SB(); MF(1, 1); A2(load_b(bnext, 0, t + 1); load_b(bnext, 5, t + 1));
+            SB(); MF(2, 1); A2(load_b(bnext, 1, t + 1); load_b(bnext, 2, t + 1));
+            SB(); MF(1, 2); A2(load_b(bnext, 3, t + 1); load_b(bnext, 4, t + 1));
+            SB(); MF(2, 2);
+            SB(); MF(1, 3);
+            SB(); MF(2, 3);
+            SB(); MF(3, 0); A8(cV12());
+            SB(); MF(4, 0); A1(store_raw(rset[par], par));
+            SB(); MF(3, 1); A1(load_raw(rset[par], t + 4));
+            SB(); MF(4, 1);
+            SB(); MF(3, 2);
+            SB(); MF(4, 2);
+            SB(); MF(3, 3);
+            SB(); MF(4, 3);
+            SB();
+        } else {
+            // two MFMAs per MF(): the weights of a position pair are re-loaded (for chunk t+1, into the same registers) right
+            // after its last MFMA, 32 MFMAs ahead of their use; the pieces sit two MFMAs apart
+            SB(); MF(0, 0); A8(cV34());
+            SB(); MF(5, 0); A8(rdA(par ^ 1));
+            SB(); MF(0, 1);
+            SB(); MF(5, 1); A8(cTA());
+            SB(); MF(0, 2); A8(rdB(par ^ 1));
+            SB(); MF(5, 2);
+            SB(); MF(0, 3); A8(cTB());
+            SB(); MF(5, 3);
+            SB(); MF(1, 0); A8(cV05());
+            SB(); MF(2, 0); A2(load_b(bcur, 0, t + 1));
+            SB(); MF(1, 1); A2(load_b(bcur, 5, t + 1));
+            SB(); MF(2, 1); A1(store_raw(rset[0], par));
+            SB(); MF(1, 2); A1(load_raw(rset[0], t + 3));
+            SB(); MF(2, 2);
+            SB(); MF(1, 3);
+            SB(); MF(2, 3);
+            SB(); MF(3, 0); A8(cV12());
+            SB(); MF(4, 0); A2(load_b(bcur, 1, t + 1));
+            SB(); MF(3, 1); A2(load_b(bcur, 2, t + 1));
+            SB(); MF(4, 1);
+            SB(); MF(3, 2);
+            SB(); MF(4, 2);
+            SB(); MF(3, 3);
+            SB(); MF(4, 3); A2(load_b(bcur, 3, t + 1); load_b(bcur, 4, t + 1));
+            SB();
+        }
         if (!(SEAM_W24_ABL & 4)) __syncthreads();
     };
     for (int t = 0; t < p.nchunks; t += 2) {
-        chunk(t, 0, bfs[0], bfs[1]);
-        if (t + 1 < p.nchunks) chunk(t + 1, 1, bfs[1], bfs[0]);
+        chunk(t, 0, bfs[0], bfs[NBS - 1]);
+        if (t + 1 < p.nchunks) chunk(t + 1, 1, bfs[NBS - 1], bfs[0]);
     }
 #undef SB
 #undef MF
@@ -468,55 +428,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(const Wino24Args p) {
         (void*)((const char*)(p.res ? p.res : p.y) + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
     const int et = tid >> 3;          // tile of the exchange this thread finishes
     const int n4 = tid & 7;
-    const int ncol = tn * 32 + n4 * 4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + ncol);
-    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + ncol);
     int g, tyt, txt, prow_unused;
     const bool tile_ok = slot(et, g, tyt, txt, prow_unused) && g < n_here;
     const int oy = 2 * tyt, ox = 4 * txt;
     const int cstep = p.K * 4, rstep = p.Wo * cstep;                      // bytes per output pixel / row
-    const unsigned obase = (unsigned)(((g * p.Ho + oy) * p.Wo + ox) * p.K + ncol) * 4u;
-    // nu half (A4t) on register PAIRS (acc[nu][r], acc[nu][r+1] are adjacent VGPRs): packed fp32, half the VALU instructions
-    f32x2 yy[4][8];
-    {
-        const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const f32x2 m0 = {acc[0][2 * h], acc[0][2 * h + 1]}, m1 = {acc[1][2 * h], acc[1][2 * h + 1]};
-            const f32x2 m2 = {acc[2][2 * h], acc[2][2 * h + 1]}, m3 = {acc[3][2 * h], acc[3][2 * h + 1]};
-            const f32x2 m4 = {acc[4][2 * h], acc[4][2 * h + 1]}, m5 = {acc[5][2 * h], acc[5][2 * h + 1]};
-            const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
-            yy[0][h] = pk_add(pk_add(m0, s12), s34);
-            yy[1][h] = pk_fma_s(c2, d34, d12);
-            yy[2][h] = pk_fma_s(c4, s34, s12);
-            yy[3][h] = pk_add(pk_fma_s(c8, d34, d12), m5);
-        }
-    }
-#pragma unroll
-    for (int bp = 0; bp < 2; ++bp) {
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ncol = (tn * NT + nt) * 32 + n4 * 4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + ncol);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + ncol);
+        const unsigned obase = (unsigned)(((g * p.Ho + oy) * p.Wo + ox) * p.K + ncol) * 4u;
         __syncthreads();              // previous readers of `ex` (first pass: of the raw buffers it aliases) are done
+        // nu half (A4t) on register PAIRS (acc[nu][nt][r], [r+1] are adjacent registers): packed fp32; each pair goes straight to LDS
+        {
+            const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const int r = 2 * h;
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float* e0 = &ex[((xi * 2 + 0) * 32 + row) * 32 + (lane & 31)];
-            e0[0] = yy[2 * bp][h][0];
-            e0[32] = yy[2 * bp][h][1];
-            e0[32 * 32] = yy[2 * bp + 1][h][0];
-            e0[32 * 32 + 32] = yy[2 * bp + 1][h][1];
+            for (int h = 0; h < 8; ++h) {
+                const f32x2 m0 = {acc[0][nt][2 * h], acc[0][nt][2 * h + 1]}, m1 = {acc[1][nt][2 * h], acc[1][nt][2 * h + 1]};
+                const f32x2 m2 = {acc[2][nt][2 * h], acc[2][nt][2 * h + 1]}, m3 = {acc[3][nt][2 * h], acc[3][nt][2 * h + 1]};
+                const f32x2 m4 = {acc[4][nt][2 * h], acc[4][nt][2 * h + 1]}, m5 = {acc[5][nt][2 * h], acc[5][nt][2 * h + 1]};
+                const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
+                const f32x2 y0 = pk_add(pk_add(m0, s12), s34);
+                const f32x2 y1 = pk_fma_s(c2, d34, d12);
+                const f32x2 y2 = pk_fma_s(c4, s34, s12);
+                const f32x2 y3 = pk_add(pk_fma_s(c8, d34, d12), m5);
+                const int r = 2 * h;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* e0 = &ex[((xi * 4 + 0) * 32 + row) * 32 + (lane & 31)];
+                e0[0] = y0[0];               e0[32] = y0[1];
+                e0[1024] = y1[0];            e0[1024 + 32] = y1[1];
+                e0[2048] = y2[0];            e0[2048 + 32] = y2[1];
+                e0[3072] = y3[0];            e0[3072 + 32] = y3[1];
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(&ex[((1 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
-            const f32x4 q2 = *reinterpret_cast<const f32x4*>(&ex[((2 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
-            const f32x4 q3 = *reinterpret_cast<const f32x4*>(&ex[((3 * 2 + bb) * 32 + et) * 32 + n4 * 4]);
+        for (int bcol = 0; bcol < 4; ++bcol) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(&ex[((1 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(&ex[((2 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q3 = *reinterpret_cast<const f32x4*>(&ex[((3 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
             f32x4 yv[2];
             yv[0] = q0 + q1 + q2;
             yv[1] = q1 - q2 - q3;
-            const int bcol = 2 * bp + bb;
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) {
                 const bool ok = tile_ok && (oy + aa) < p.Ho && (ox + bcol) < p.Wo;
@@ -690,6 +645,16 @@ inline Layout choose_layout(int N, int tiles_x, int tiles_y, size_t in_img_bytes
 
 inline bool wino_ok(int C, int K, int R, int S, int stride) { return R == 3 && S == 3 && stride == 1 && C % 8 == 0 && K % 32 == 0 && C >= 8; }
 
+// n-tiles per block.  NT = 2 (one block per CU, 192 accumulators in AccVGPRs, every A fragment and the raw patch feeding twice
+// the MFMAs) is built and parity-clean but NOT the default: as compiled by hipcc 7.2 it ties on the 200^2 layers and loses
+// 3-13 % elsewhere -- the register allocator parks the loop-invariant LDS / load addresses and 8 transform registers in spare
+// AccVGPRs and re-reads them (~60 v_accvgpr_read per 96 MFMAs) although ~90 arch VGPRs stay unused in the loop, and an asm MFMA
+// with pinned register classes did not change that.  SEAM_W24_NT=2 enables it for experiments.
+inline int wino24_nt(int K) {
+    static const int force = getenv("SEAM_W24_NT") ? atoi(getenv("SEAM_W24_NT")) : 1;
+    return (force == 2 && K % 64 == 0) ? 2 : 1;
+}
+
 int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long& blocks) {
     if (!wino_ok(C, K, 3, 3, 1) || N <= 0) return (int)hipErrorInvalidValue;
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K;
@@ -698,7 +663,7 @@ int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long&
     if ((size_t)H * W * C * 4 >= kOob || (size_t)a.Ho * a.Wo * K * 4 >= kOob) return (int)hipErrorInvalidValue;
     const int tiles_x = (a.Wo + 3) / 4, tiles_y = (a.Ho + 1) / 2;
     const Layout pp = choose_layout(N, tiles_x, tiles_y, (size_t)H * W * C * 4, (size_t)a.Ho * a.Wo * K * 4);
-    a.tiles_n = K / 32;
+    a.tiles_n = K / (32 * wino24_nt(K));
     a.nchunks = C / 8;
     a.nreg = pp.nreg; a.G = pp.G; a.per_img = (int)pp.per_img;
     a.stack = pp.stack; a.PH = pp.PH; a.tiles_y = tiles_y;
@@ -736,7 +701,7 @@ long long seam_wino24_issue_slots(int N, int H, int W, int C, int K, int pad) {
     Wino24Args a;
     long blocks;
     if (wino24_plan(a, N, H, W, C, K, pad, blocks)) return 0;
-    return (long long)blocks * 32 * 24;
+    return (long long)blocks * wino24_nt(K) * 32 * 24;
 }
 
 int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* scale, const float* shift, const float* residual,
@@ -747,7 +712,9 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
     if (rc) return rc;
     a.x = x; a.u = u_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.relu = relu;
-    hipLaunchKernelGGL(conv3x3_wino24, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    static const int dyn = getenv("SEAM_W24_DYNLDS") ? atoi(getenv("SEAM_W24_DYNLDS")) : 0;     // dev knob: occupancy experiments
+    if (wino24_nt(K) == 2) hipLaunchKernelGGL(conv3x3_wino24<2>, dim3((unsigned)blocks), dim3(256), dyn, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3x3_wino24<1>, dim3((unsigned)blocks), dim3(256), dyn, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
