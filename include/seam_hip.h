@@ -86,6 +86,15 @@ int seam_conv2d_upres_f32(const float* x, const float* w_packed, const float* sc
                           const float* top, float* y, int N, int H, int W, int C, int K, int R, int S,
                           int stride, int pad, int Ht, int Wt, int relu, seam_stream_t stream);
 
+/* ResNet downsample blocks [TV Bottleneck.forward: out = relu(bn3(conv3(h)) + bn_d(conv_d(x)))] as ONE GEMM over two 1x1
+ * sources: y[n,ho,wo,:] = act(W[:, :C1] . x1[n,ho,wo,:] + W[:, C1:] . x2[n,ho*stride2,wo*stride2,:] (* scale) + shift).
+ * x1 NHWC [N,Ho,Wo,C1], x2 NHWC [N,H2,W2,C2], C1 and C2 multiples of 32; w_packed = seam_pack_conv_weight_f32 of the
+ * [K, C1+C2, 1, 1] weight (the host folds the two FrozenBN scales into it and adds the shifts).  The shortcut branch is
+ * never written to memory and read back as a residual. */
+int seam_conv2d_dual_f32(const float* x1, const float* x2, const float* w_packed, const float* scale,
+                         const float* shift, float* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2,
+                         int stride2, int K, int relu, seam_stream_t stream);
+
 /* fp16 variant (BASELINE config 5: "fp16 MFMA path with fp32 ... accumulation"): x, w_packed,
  * residual are IEEE fp16 (NHWC, C multiple of 8 and, when C >= 64, of 64); v_mfma_f32_32x32x16_f16
  * with fp32 accumulators; scale/shift stay fp32; y is fp16, or fp32 when y_f32 != 0 (the last trunk

@@ -58,11 +58,16 @@ struct ConvArgs {
     int y_f32;         // fp16 kernel only: write fp32 output (descriptor heads stay fp32)
     int slab_bn;       // rows per packed weight slab (128 or 64; fixed at pack time, >= the tile's BN)
     int tiles_m, tiles_n;
+    // DUAL kernels (fp32): the reduction runs over TWO 1x1 sources -- chunks [0, C/32) from x [N,Ho,Wo,C] (stride 1) and the rest
+    // from x2 [N,H2,W2,C2] sampled at (ho*stride2, wo*stride2); kred = C + C2.  ResNet downsample blocks: bn3(conv3(h)) +
+    // bn_d(conv_d(x)) as ONE GEMM (scales folded into the weights), so the shortcut never goes to memory and back.
+    const void* x2;
+    int H2, W2, C2, stride2;
     int rH, rW;        // > 0 (fp32, K % 4 == 0 only): `res` is a coarser map [N, rH, rW, K] added through a nearest-neighbour
                        // upsample to [Ho, Wo] (ATen: src = min(floor(dst * rH / Ho), rH - 1)) -- the FPN top-down merge
 };
 
-template <typename T, int BM, int BN, int NW>
+template <typename T, int BM, int BN, int NW, bool DUAL = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const ConvArgs p) {
     constexpr bool F16 = sizeof(T) == 2;
     constexpr int ES = (int)sizeof(T);
@@ -99,8 +104,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
 
     // per-tile loader state (rewritten by setup())
     int m0, n0;
-    __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
+    __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc, a2_rsrc;
     int arow[AI], ahi[AI], awi[AI];      // byte offset of the (r=0,s=0,c=0) tap; top-left input coordinate
+    unsigned arow1[DUAL ? AI : 1], arow2[DUAL ? AI : 1];     // DUAL: byte offset of this row's pixel in source 1 / 2 (kOob: no row)
+    const int nk1 = DUAL ? p.C / BKE : 0;                    // DUAL: chunks that come from source 1
     int kc, kr, ks, tapoff;
     // Number of the chunk being fetched.  Derived from kernel arguments only, so the weight-slab
     // offset below is provably wave-uniform (an SGPR soffset; a lane-tainted value would put every
@@ -123,6 +130,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
             (void*)((const char*)p.x + (size_t)n_first * img_elems * ES), 0,
             (int)(rem_bytes > kOob ? kOob : (unsigned)rem_bytes), 0x00020000);
         // weight slabs are [n_slab][chunk][slab_bn][128 B]; a BN < slab_bn tile reads its rows inside each slab
+        if constexpr (DUAL) {
+            const size_t img2 = (size_t)p.H2 * p.W2 * p.C2;
+            const size_t rem2 = ((size_t)(p.N - n_first) * img2) * ES;
+            a2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x2 + (size_t)n_first * img2 * ES), 0,
+                                                        (int)(rem2 > kOob ? kOob : (unsigned)rem2), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int m = m0 + lrow + RP * i;
+                const int n = m / HoWo;
+                const int rm = m - n * HoWo;
+                const int ho = rm / p.Wo;
+                const int wo = rm - ho * p.Wo;
+                const bool ok = m < p.M;
+                arow1[i] = ok ? (unsigned)(((((n - n_first) * p.Ho + ho) * p.Wo + wo) * p.C) * ES + lcol * 16) : kOob;
+                arow2[i] = ok ? (unsigned)(((((n - n_first) * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.C2) * ES + lcol * 16) : kOob;
+            }
+        }
         const int n_in_slab = n0 % p.slab_bn;
         b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)((const char*)p.w + (size_t)(n0 - n_in_slab) * p.kred * ES + (size_t)n_in_slab * CHUNK_BYTES), 0,
@@ -165,6 +189,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
     constexpr int P = F16 ? 6 : 2;               // unroll period = lcm(2 LDS buffers, D sets): all indices static
     f32x4 areg[D][AI], breg[D][BI];
     auto load_a = [&](f32x4 (&ar)[AI], int i) {
+        if constexpr (DUAL) {      // chunk uq of source 1, or chunk uq - nk1 of source 2 (uq is wave-uniform: scalar selects)
+            const bool first = uq < nk1;
+            const unsigned off = (first ? arow1[i] : arow2[i]) + (unsigned)((first ? uq : uq - nk1) * CHUNK_BYTES);
+            ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(first ? a_rsrc : a2_rsrc, off, 0, 0));   // ONE unconditional load
+            return;
+        }
         const bool ok = (unsigned)(ahi[i] + kr) < (unsigned)p.H && (unsigned)(awi[i] + ks) < (unsigned)p.W && kr < p.R;
         const unsigned off = ok ? (unsigned)(arow[i] + tapoff) : kOob;
         ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0));
@@ -175,6 +205,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
     };
     auto advance_k = [&]() {     // move on by one chunk
         ++uq;
+        if constexpr (DUAL) return;
         if (p.C >= BKE) {           // chunk order (r, c-chunk, s)
             if (++ks == p.S) {
                 ks = 0;
@@ -854,10 +885,12 @@ inline void choose_tile(int prec, int M, int K, int& best_bm, int& best_bn) {
         }
 }
 
+struct DualSrc { const void* x2; int H2, W2, C2, stride2; };
+
 template <typename T>
 int conv2d(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, int y_f32, void* stream,
-           int rH = 0, int rW = 0) {
+           int rH = 0, int rW = 0, const DualSrc* dual = nullptr) {
     constexpr int BKE = CHUNK_BYTES / (int)sizeof(T), EPV = 16 / (int)sizeof(T);
     if ((C % EPV) || (C >= BKE && C % BKE) || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     ConvArgs a;
@@ -871,6 +904,14 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.relu = relu;
     a.y_f32 = y_f32;
     a.rH = rH; a.rW = rW;
+    a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
+    if (dual) {
+        if (sizeof(T) != 4 || R != 1 || S != 1 || stride != 1 || pad != 0 || (C % BKE) || (dual->C2 % BKE) || dual->stride2 < 1 ||
+            (a.Ho - 1) * dual->stride2 >= dual->H2 || (a.Wo - 1) * dual->stride2 >= dual->W2 || !dual->x2)
+            return (int)hipErrorInvalidValue;
+        a.x2 = dual->x2; a.H2 = dual->H2; a.W2 = dual->W2; a.C2 = dual->C2; a.stride2 = dual->stride2;
+        a.kred = C + dual->C2;
+    }
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
     if (rH > 0 && (sizeof(T) != 4 || (K & 3) || rW <= 0 || !residual || relu == 2)) return (int)hipErrorInvalidValue;
     const int rows = ((K + 63) / 64) * 64;
@@ -887,6 +928,16 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     const dim3 grid(ntiles < slots ? ntiles : slots);
     static const int dyn = getenv("SEAM_CONV_DYNLDS") ? atoi(getenv("SEAM_CONV_DYNLDS")) : 0;   // dev knob: occupancy experiments
     hipStream_t st = (hipStream_t)stream;
+    if constexpr (sizeof(T) == 4) {
+        if (dual) {
+            if (best_bm == 256) return (int)hipErrorInvalidValue;      // (never chosen for fp32)
+            if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 128, 4, true>), grid, dim3(256), dyn, st, a);
+            else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 64, 4, true>), grid, dim3(256), dyn, st, a);
+            else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 64, 128, 4, true>), grid, dim3(256), dyn, st, a);
+            else hipLaunchKernelGGL((conv_igemm<T, 64, 64, 4, true>), grid, dim3(256), dyn, st, a);
+            return (int)hipGetLastError();
+        }
+    }
     if (best_bm == 256) hipLaunchKernelGGL((conv_igemm<T, 256, 128, 8>), grid, dim3(512), dyn, st, a);
     else if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 128, 4>), grid, dim3(256), dyn, st, a);
     else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 64, 4>), grid, dim3(256), dyn, st, a);
@@ -909,6 +960,7 @@ int conv2d_bx3(const void* x, const void* w_packed, const float* scale, const fl
     a.relu = relu;
     a.y_f32 = 1;
     a.rH = 0; a.rW = 0;
+    a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
     const int rows = ((K + 63) / 64) * 64;
     a.slab_bn = rows % 128 == 0 ? 128 : 64;
@@ -965,6 +1017,13 @@ int seam_conv2d_upres_f32(const float* x, const float* w_packed, const float* sc
                           int relu, void* stream) {
     if (Ht <= 0 || Wt <= 0) return (int)hipErrorInvalidValue;
     return conv2d<float>(x, w_packed, scale, shift, top, y, N, H, W, C, K, R, S, stride, pad, relu, 1, stream, Ht, Wt);
+}
+
+int seam_conv2d_dual_f32(const float* x1, const float* x2, const float* w_packed, const float* scale, const float* shift,
+                         float* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int stride2, int K, int relu,
+                         void* stream) {
+    const DualSrc d = {x2, H2, W2, C2, stride2};
+    return conv2d<float>(x1, w_packed, scale, shift, nullptr, y, N, Ho, Wo, C1, K, 1, 1, 1, 0, relu, 1, stream, 0, 0, &d);
 }
 
 int seam_conv2d_f16(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual,

@@ -106,6 +106,13 @@ class FrozenBatchNorm2d(nn.Module):
         return (self.weight, self.bias, self.running_mean, self.running_var)
 
 
+# Projection-shortcut blocks (first block of each ResNet layer) as one dual-source GEMM (ops.conv2d_dual).  The two
+# FrozenBN scales are folded into the weights, so results differ from the two-launch form by ~1e-7 relative (one extra
+# rounding per weight); SEAM_FUSE_SHORTCUT=0 keeps the two launches.
+import os as _os
+FUSE_SHORTCUT = _os.environ.get("SEAM_FUSE_SHORTCUT", "1") != "0"
+
+
 class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride, downsample):
         super().__init__()
@@ -155,6 +162,9 @@ class ResNet50Body(nn.Module):
                         if b.downsample is not None:
                             e["ds"] = ops.pack_conv(b.downsample[0].weight, None, b.downsample[1].tensors(),
                                                     stride=b.stride, bn_eps=b.downsample[1].eps, dtype=dt)
+                            if dt == torch.float32 and FUSE_SHORTCUT:     # conv3 + projection shortcut as one GEMM
+                                e["c3ds"] = ops.pack_conv_dual(b.conv3.weight, b.bn3.tensors(), b.downsample[0].weight,
+                                                               b.downsample[1].tensors(), bn_eps=b.bn3.eps)
                         pk[(li, bi)] = e
             self._pk, self._pk_key = pk, key
         return self._pk
@@ -170,6 +180,9 @@ class ResNet50Body(nn.Module):
                 e = pk[(li, bi)]
                 o = ops.conv2d(x, e["c1"], relu=True)
                 o = ops.conv2d(o, e["c2"], relu=True)
+                if "c3ds" in e:       # projection-shortcut block: bn3(conv3(o)) + bn_d(conv_d(x)) + ReLU in one launch
+                    x = ops.conv2d_dual(o, x, e["c3ds"], getattr(self, f"layer{li}")[bi].stride, relu=True)
+                    continue
                 idt = ops.conv2d(x, e["ds"]) if "ds" in e else x
                 x = ops.conv2d(o, e["c3"], relu=True, residual=idt)   # bn3 + add + ReLU fused
             feats.append(x)

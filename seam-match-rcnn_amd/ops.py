@@ -410,6 +410,51 @@ def conv2d_topdown(x: torch.Tensor, pc: PackedConv, top: torch.Tensor) -> torch.
     return y
 
 
+def pack_conv_dual(w1: torch.Tensor, bn1, w2: torch.Tensor, bn2, bn_eps: float = 1e-5) -> PackedConv:
+    """Weights of ``conv2d_dual``: two 1x1 convs, each followed by its own (Frozen)BatchNorm, summed.
+    The scales are folded into the weights (one fp32 rounding per weight) and the shifts added:
+    bn_a(W_a . h) + bn_b(W_b . x) = [s_a W_a | s_b W_b] . [h ; x] + (t_a + t_b)."""
+    def fold(w, bn):
+        bw, bb, rm, rv = (t.detach().to(F32) for t in bn)
+        sc = bw * torch.rsqrt(rv + bn_eps)
+        return w.detach().to(F32).reshape(w.shape[0], -1) * sc[:, None], bb - rm * sc
+    wa, ta = fold(w1, bn1)
+    wb, tb = fold(w2, bn2)
+    w = torch.cat([wa, wb], 1).contiguous()
+    return pack_conv(w[:, :, None, None], (ta + tb).contiguous(), wino=False)
+
+
+def conv2d_dual(x1: torch.Tensor, x2: torch.Tensor, pc: PackedConv, stride2: int = 1, relu: bool = False) -> torch.Tensor:
+    """y = act(W[:, :C1] . x1 + W[:, C1:] . x2[:, ::stride2, ::stride2] + shift) in ONE launch (``seam_conv2d_dual_f32``):
+    the residual block with a projection shortcut [TV Bottleneck.forward] without writing the shortcut branch to memory.
+    x1 NHWC [N,Ho,Wo,C1], x2 NHWC [N,H2,W2,C2] -> NHWC [N,Ho,Wo,K]; exact fp32."""
+    x1 = _req(x1, None, "x1")
+    x1, x2 = _req(x1, F32, "x1"), _req(x2, F32, "x2")
+    if pc.dtype != F32 or pc.R != 1 or pc.S != 1:
+        raise ValueError("conv2d_dual: needs fp32 1x1 weights from pack_conv_dual")
+    n, ho, wo, c1 = x1.shape
+    n2, h2, w2, c2 = x2.shape
+    if n2 != n or c1 + c2 != pc.Cstore or c1 % 32 or c2 % 32:
+        raise ValueError("conv2d_dual: channel / batch mismatch (C1, C2 must be multiples of 32 and sum to the packed width)")
+    if (ho - 1) * stride2 >= h2 or (wo - 1) * stride2 >= w2:
+        raise ValueError("conv2d_dual: x2 too small for the output grid")
+    y = torch.empty((n, ho, wo, pc.K), dtype=F32, device=x1.device)
+    trace = CONV_TRACE
+    if trace is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib = _native.lib()
+    _native.check(lib.seam_conv2d_dual_f32(_ptr(x1), _ptr(x2), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, ho, wo, c1,
+                                           h2, w2, c2, stride2, pc.K, int(relu), _stream()), "seam_conv2d_dual_f32")
+    if trace is not None:
+        e1.record()
+        tile = lib.seam_conv_tile_prec(0, n * ho * wo, pc.K)
+        trace.append((f"conv_igemm<float,{tile // 1000},{tile % 1000}>", 2.0 * n * ho * wo * pc.K * (c1 + c2), e0, e1,
+                      (n, ho, wo, c1 + c2, pc.K, 1, 1),
+                      float(4 * (x1.numel() + n * ho * wo * c2 + pc.w.numel() + y.numel()))))
+    return y
+
+
 def linear(x: torch.Tensor, pc: PackedConv, relu: bool = False, out_f32: bool = False) -> torch.Tensor:
     """[M,C] x packed [K,C] -> [M,K] through the conv kernel (1x1 on a 1x1 map)."""
     m, c = x.shape

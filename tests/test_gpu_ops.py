@@ -168,6 +168,33 @@ def test_conv_topdown_fused(ops, shape):
     assert_close(got.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 20, 24, 64, 1, 256), (2, 128, 13, 17, 256, 2, 512), (5, 32, 7, 9, 96, 2, 64),
+                                   (1, 512, 25, 25, 1024, 2, 2048)])
+def test_conv_dual_source(ops, shape):
+    """Projection-shortcut block as one GEMM over two 1x1 sources == bn3(conv3(h)) + bn_d(conv_d(x)) + ReLU (torch),
+    and == the two-launch form of the same ops within the rounding of the folded scales."""
+    d = dev()
+    n, c1, ho, wo, c2, s2, k = shape
+    h = rnd(70, (n, c1, ho, wo))
+    x = rnd(71, (n, c2, ho * s2 - (s2 - 1), wo * s2 - (s2 - 1)))            # odd input size for stride 2
+    w3, wd = rnd(72, (k, c1, 1, 1), "w3") / (c1 ** 0.5), rnd(73, (k, c2, 1, 1), "wd") / (c2 ** 0.5)
+    def bn(seed):
+        return (torch.from_numpy(synth.uniform(synth.stream_id(seed, "bw"), (k,), 0.5, 1.5)), rnd(seed + 1, (k,), "bb") * 0.1,
+                rnd(seed + 2, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(seed + 3, "rv"), (k,), 0.5, 1.5)))
+    b3, bd = bn(74), bn(78)
+    def fbn(y, b):
+        sc = b[0] * (b[3] + 1e-5).rsqrt()
+        return y * sc[None, :, None, None] + (b[1] - b[2] * sc)[None, :, None, None]
+    ref = F.relu(fbn(F.conv2d(h, w3), b3) + fbn(F.conv2d(x, wd, None, s2), bd))
+    pc = ops.pack_conv_dual(w3.to(d), tuple(t.to(d) for t in b3), wd.to(d), tuple(t.to(d) for t in bd))
+    got = ops.conv2d_dual(nhwc(h).to(d), nhwc(x).to(d), pc, s2, relu=True)
+    assert_close(got.permute(0, 3, 1, 2), ref)
+    p3 = ops.pack_conv(w3.to(d), None, tuple(t.to(d) for t in b3))
+    pd = ops.pack_conv(wd.to(d), None, tuple(t.to(d) for t in bd), stride=s2)
+    two = ops.conv2d(nhwc(h).to(d), p3, relu=True, residual=ops.conv2d(nhwc(x).to(d), pd))
+    assert float((got - two).abs().max()) <= 2e-5 * float(two.abs().max())
+
+
 def test_preprocess_batched_clip_tensor(ops):
     """The frames of one clip tensor (same-shape views at a constant stride) go through ONE launch; identical to the
     per-image launches."""
