@@ -111,6 +111,7 @@ class FrozenBatchNorm2d(nn.Module):
 # rounding per weight); SEAM_FUSE_SHORTCUT=0 keeps the two launches.
 import os as _os
 FUSE_SHORTCUT = _os.environ.get("SEAM_FUSE_SHORTCUT", "1") != "0"
+BODY_STREAMS = int(_os.environ.get("SEAM_BODY_STREAMS", "1"))      # ResNet body: batch slices on this many HIP streams
 
 
 class Bottleneck(nn.Module):
@@ -172,11 +173,39 @@ class ResNet50Body(nn.Module):
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         """x NHWC4 [N,H,W,4] -> [C2, C3, C4, C5] NHWC."""
         pk = self.packed()
+        n = x.shape[0]
+        if BODY_STREAMS >= 2 and n >= 2 * BODY_STREAMS and x.is_cuda:
+            # The batch in BODY_STREAMS slices on as many HIP streams, each writing its slice of the stage outputs: while one
+            # slice sits in an HBM-bound layer (the 1x1 expansions with their residual) another one runs an MFMA-bound layer on
+            # the same CUs.  Per-image results do not depend on the batch an image rides in (tested), so this is the same math.
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_streams", None) is None or len(self._streams) != BODY_STREAMS:
+                self._streams = [torch.cuda.Stream(device=x.device) for _ in range(BODY_STREAMS)]
+            h1, w1 = (x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1
+            hh, ww = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
+            outs = []
+            for li, (nblk, planes, stride) in enumerate(RESNET50_LAYERS, start=1):
+                if stride == 2:
+                    hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+                outs.append(torch.empty((n, hh, ww, planes * 4), dtype=x.dtype, device=x.device))
+            bounds = [n * i // BODY_STREAMS for i in range(BODY_STREAMS + 1)]
+            for i, st in enumerate(self._streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    lo, hi = bounds[i], bounds[i + 1]
+                    self._run(x[lo:hi], pk, [o[lo:hi] for o in outs])
+            for st in self._streams:
+                cur.wait_stream(st)
+            return outs
+        return self._run(x, pk, None)
+
+    def _run(self, x, pk, outs):
         x = ops.conv2d(x, pk["stem"], relu=True)               # 7x7/s2 + FrozenBN + ReLU
         x = ops.maxpool2d(x, 3, 2, 1)
         feats = []
         for li in range(1, 5):
-            for bi in range(len(getattr(self, f"layer{li}"))):
+            nblk = len(getattr(self, f"layer{li}"))
+            for bi in range(nblk):
                 e = pk[(li, bi)]
                 o = ops.conv2d(x, e["c1"], relu=True)
                 o = ops.conv2d(o, e["c2"], relu=True)
@@ -184,7 +213,8 @@ class ResNet50Body(nn.Module):
                     x = ops.conv2d_dual(o, x, e["c3ds"], getattr(self, f"layer{li}")[bi].stride, relu=True)
                     continue
                 idt = ops.conv2d(x, e["ds"]) if "ds" in e else x
-                x = ops.conv2d(o, e["c3"], relu=True, residual=idt)   # bn3 + add + ReLU fused
+                x = ops.conv2d(o, e["c3"], relu=True, residual=idt,   # bn3 + add + ReLU fused
+                               out=outs[li - 1] if (outs is not None and bi == nblk - 1) else None)
             feats.append(x)
         return feats
 

@@ -112,10 +112,11 @@ _WINO_FILL = {}
 
 
 def _wino_pays(lib, n, h, w, c, k, pad) -> bool:
-    key = (n, h, w, c, k, pad)
+    # decided on the map geometry alone (a canonical batch of 256 images), like _wino24_pays: batch-independent results
+    key = (h, w, c, k, pad)
     f = _WINO_FILL.get(key)
     if f is None:
-        f = _WINO_FILL[key] = int(lib.seam_wino_slot_fill_pct(n, h, w, c, k, pad))
+        f = _WINO_FILL[key] = int(lib.seam_wino_slot_fill_pct(256, h, w, c, k, pad))
     return f >= WINO_MIN_FILL
 
 

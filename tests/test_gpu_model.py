@@ -118,6 +118,26 @@ def test_backbone_fpn_rpn_head(model_and_state):
         assert_close(dlt.permute(0, 3, 1, 2), od)
 
 
+def test_body_on_two_streams_is_bit_identical(model_and_state):
+    """SEAM_BODY_STREAMS knob: the ResNet body over batch slices on two HIP streams == one stream, bit for bit."""
+    import seam_match_rcnn_amd.models.detection as det
+    model, _ = model_and_state
+    imgs = [torch.from_numpy(synth.frames(90 + i, 1, 96, 128)[0]).to(dev()) for i in range(5)]
+    saved = model.transform.min_size, model.transform.max_size, det.BODY_STREAMS
+    model.transform.min_size, model.transform.max_size = 96, 128
+    try:
+        with torch.no_grad():
+            det.BODY_STREAMS = 1
+            one, *_ = model.extract_features(imgs)
+            det.BODY_STREAMS = 2
+            two, *_ = model.extract_features(imgs)
+        torch.cuda.synchronize()
+    finally:
+        model.transform.min_size, model.transform.max_size, det.BODY_STREAMS = saved
+    for k in one:
+        assert torch.equal(one[k], two[k]), k
+
+
 def test_fixed_roi_forward_c1(model_and_state):
     """BASELINE config 1 shape, scaled: fixed ROIs, 16-product gallery."""
     m, sd = model_and_state
