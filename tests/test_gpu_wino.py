@@ -138,3 +138,34 @@ def test_wino_batch_invariance_and_determinism(ops, form):
         ops.WINOGRAD = saved
     assert torch.equal(y5, y5b)
     assert torch.equal(y5[3:4], y1)
+
+
+def test_wino24_two_ntile_variant_in_subprocess():
+    """conv3x3_wino24<2> (two n-tiles per block, AccVGPR accumulators; opt-in with SEAM_W24_NT=2, read once at load time):
+    kept parity-clean against the implicit GEMM in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import math, torch
+import seam_match_rcnn_amd.ops as ops
+import seam_match_rcnn_amd.synth as synth
+ops.WINO_MIN_FILL = 0
+d = torch.device("cuda:0")
+worst = 0.0
+for (n, c, h, w, k, pad) in [(2, 64, 20, 24, 64, 1), (3, 256, 14, 14, 256, 1), (3, 256, 14, 14, 128, 0), (1, 32, 51, 35, 192, 1)]:
+    x = torch.from_numpy(synth.normal(synth.stream_id(5, "x"), (n, h, w, c))).to(d)
+    wt = torch.from_numpy(synth.normal(synth.stream_id(6, "w"), (k, c, 3, 3))).to(d) / math.sqrt(9 * c)
+    pc = ops.pack_conv(wt, None, stride=1, pad=pad)
+    ops.WINOGRAD, ops.WINOGRAD24 = True, 2
+    a = ops.conv2d(x, pc, True)
+    ops.WINOGRAD = False
+    b = ops.conv2d(x, pc, True)
+    worst = max(worst, float((a - b).abs().max()) / float(b.abs().max()))
+print("WORST", worst)
+assert worst < 2e-5, worst
+'''
+    env = dict(os.environ, SEAM_W24_NT="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
