@@ -86,6 +86,14 @@ int seam_conv2d_upres_f32(const float* x, const float* w_packed, const float* sc
                           const float* top, float* y, int N, int H, int W, int C, int K, int R, int S,
                           int stride, int pad, int Ht, int Wt, int relu, seam_stream_t stream);
 
+/* seam_conv2d_f32 with the output grid cropped to its top-left [Ho, Wo] (Ho, Wo <= the full output size): `pad` rows /
+ * columns of zeros before the map and fewer after it.  Call site: the ResNet stem [TV ResNet.conv1, 7x7 / stride 2 / pad 3]
+ * on the space-to-depth input written by seam_preprocess_s2d_batch_f32 -- a 4x4 / stride-1 convolution over 12 channels
+ * with 2 rows of padding before and 1 after (weights re-indexed on the host: w'[k,(dy,dx,c),r',s'] = w[k,c,2r'+dy-1,2s'+dx-1]). */
+int seam_conv2d_crop_f32(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
+                         int relu, seam_stream_t stream);
+
 /* ResNet downsample blocks [TV Bottleneck.forward: out = relu(bn3(conv3(h)) + bn_d(conv_d(x)))] as ONE GEMM over two 1x1
  * sources: y[n,ho,wo,:] = act(W[:, :C1] . x1[n,ho,wo,:] + W[:, C1:] . x2[n,ho*stride2,wo*stride2,:] (* scale) + shift).
  * x1 NHWC [N,Ho,Wo,C1], x2 NHWC [N,H2,W2,C2], C1 and C2 multiples of 32; w_packed = seam_pack_conv_weight_f32 of the
@@ -126,6 +134,11 @@ int seam_preprocess_batch_f32(const float* imgs, size_t img_stride, float* out, 
                               int out_h, int out_w, int Hp, int Wp, seam_stream_t stream);
 int seam_preprocess_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w,
                               int out_h, int out_w, int Hp, int Wp, seam_stream_t stream);
+
+/* The same transform written space-to-depth for the stem: out [n, Hp/2, Wp/2, 12], channel (dy*2+dx)*3 + c = pixel
+ * (2Y+dy, 2X+dx), colour c (Hp, Wp even). */
+int seam_preprocess_s2d_batch_f32(const float* imgs, size_t img_stride, float* out, int n, int in_h, int in_w,
+                                  int out_h, int out_w, int Hp, int Wp, seam_stream_t stream);
 
 /* Same transform fed by a uint8 HWC RGB frame [in_h,in_w,3]: fuses ToTensor (x/255, stuffs/transform.py:46-49)
  * so a clip crosses PCIe at 1 byte per sample (device side).  out: fp32 NHWC4 or, when

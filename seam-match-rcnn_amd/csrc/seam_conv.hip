@@ -890,7 +890,7 @@ struct DualSrc { const void* x2; int H2, W2, C2, stride2; };
 template <typename T>
 int conv2d(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, int y_f32, void* stream,
-           int rH = 0, int rW = 0, const DualSrc* dual = nullptr) {
+           int rH = 0, int rW = 0, const DualSrc* dual = nullptr, int ho_crop = 0, int wo_crop = 0) {
     constexpr int BKE = CHUNK_BYTES / (int)sizeof(T), EPV = 16 / (int)sizeof(T);
     if ((C % EPV) || (C >= BKE && C % BKE) || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     ConvArgs a;
@@ -899,6 +899,10 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.Ho = (H + 2 * pad - R) / stride + 1;
     a.Wo = (W + 2 * pad - S) / stride + 1;
     a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+    if (ho_crop > 0 && wo_crop > 0) {          // top-left crop of the output grid (asymmetric padding: `pad` before, less after)
+        if (ho_crop > a.Ho || wo_crop > a.Wo) return (int)hipErrorInvalidValue;
+        a.Ho = ho_crop; a.Wo = wo_crop;
+    }
     a.kred = kred_of<T>(C, R, S);
     a.M = N * a.Ho * a.Wo;
     a.relu = relu;
@@ -1017,6 +1021,12 @@ int seam_conv2d_upres_f32(const float* x, const float* w_packed, const float* sc
                           int relu, void* stream) {
     if (Ht <= 0 || Wt <= 0) return (int)hipErrorInvalidValue;
     return conv2d<float>(x, w_packed, scale, shift, top, y, N, H, W, C, K, R, S, stride, pad, relu, 1, stream, Ht, Wt);
+}
+
+int seam_conv2d_crop_f32(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N, int H,
+                         int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int relu, void* stream) {
+    if (Ho <= 0 || Wo <= 0) return (int)hipErrorInvalidValue;
+    return conv2d<float>(x, w_packed, scale, shift, nullptr, y, N, H, W, C, K, R, S, stride, pad, relu, 1, stream, 0, 0, nullptr, Ho, Wo);
 }
 
 int seam_conv2d_dual_f32(const float* x1, const float* x2, const float* w_packed, const float* scale, const float* shift,

@@ -67,6 +67,56 @@ __global__ void preprocess_kernel(const float* __restrict__ img, T* __restrict__
     *reinterpret_cast<V*>(out + ((size_t)y * Wp + x) * Vec16<T>::N) = o;
 }
 
+// The same transform written space-to-depth: out [N, Hp/2, Wp/2, 12], channel (dy*2 + dx)*3 + c = pixel (2Y+dy, 2X+dx), colour c.
+// The 7x7 / stride-2 stem then is a 4x4 / stride-1 convolution over 12 channels (192 reduction steps = 6 chunks exactly, no
+// padded 4th colour channel: the NHWC4 form spends 224 steps on 147 products) whose gathers are 48-byte pixels.
+template <typename T>
+__global__ void preprocess_s2d_kernel(const float* __restrict__ img, T* __restrict__ out, int in_h, int in_w,
+                                      int out_h, int out_w, int Hp, int Wp, size_t img_stride) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Y = blockIdx.y;
+    const int W2 = Wp >> 1, H2 = Hp >> 1;
+    if (X >= W2) return;
+    img += (size_t)blockIdx.z * img_stride;
+    float o[12];
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int y = 2 * Y + (d >> 1), x = 2 * X + (d & 1);
+        float v[3] = {0.f, 0.f, 0.f};
+        if (y < out_h && x < out_w) {
+            if (out_h == in_h && out_w == in_w) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = (img[((size_t)c * in_h + y) * in_w + x] - mean[c]) / stdv[c];
+            } else {
+                int y0, y1, x0, x1;
+                float ly, lx;
+                bilinear_axis(y, in_h, out_h, y0, y1, ly);
+                bilinear_axis(x, in_w, out_w, x0, x1, lx);
+                const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* p = img + (size_t)c * in_h * in_w;
+                    const float v00 = (p[(size_t)y0 * in_w + x0] - mean[c]) / stdv[c];
+                    const float v01 = (p[(size_t)y0 * in_w + x1] - mean[c]) / stdv[c];
+                    const float v10 = (p[(size_t)y1 * in_w + x0] - mean[c]) / stdv[c];
+                    const float v11 = (p[(size_t)y1 * in_w + x1] - mean[c]) / stdv[c];
+                    v[c] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[d * 3 + c] = v[c];
+    }
+    T* dst = out + (((size_t)blockIdx.z * H2 + Y) * W2 + X) * 12;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        f32x4 v4 = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(dst + 4 * q) = v4;
+    }
+}
+
 // uint8 HWC RGB frame -> ToTensor (/255, ref stuffs/transform.py:46-49) + the transform above, one pass:
 // the clip crosses PCIe as 1 byte per sample instead of 4 (row f4, device side).
 template <typename T>
@@ -266,6 +316,15 @@ int seam_preprocess_batch_f32(const float* imgs, size_t img_stride, float* out, 
 int seam_preprocess_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w, int out_h, int out_w,
                               int Hp, int Wp, void* stream) {
     return preprocess<_Float16>(imgs, out, in_h, in_w, out_h, out_w, Hp, Wp, stream, n, img_stride);
+}
+
+int seam_preprocess_s2d_batch_f32(const float* imgs, size_t img_stride, float* out, int n, int in_h, int in_w, int out_h, int out_w,
+                                  int Hp, int Wp, void* stream) {
+    if (n < 1 || n > 65535 || (Hp & 1) || (Wp & 1)) return (int)hipErrorInvalidValue;
+    dim3 grid((Wp / 2 + 127) / 128, Hp / 2, n);
+    hipLaunchKernelGGL(preprocess_s2d_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, imgs, out, in_h, in_w, out_h, out_w,
+                       Hp, Wp, img_stride);
+    return (int)hipGetLastError();
 }
 
 int seam_preprocess_u8(const uint8_t* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, int out_f16,

@@ -207,8 +207,8 @@ class VideoMatchRCNN(nn.Module):
 
     # ---- stages ------------------------------------------------------------------------------------
     def extract_features(self, images: Sequence[torch.Tensor]):
-        x, sizes, orig = self.transform(images)
-        return self.backbone(x), sizes, orig, (x.shape[1], x.shape[2])
+        x, sizes, orig, padded = self.transform(images)
+        return self.backbone(x), sizes, orig, padded
 
     def postprocess(self, result, sizes, orig):
         for r, sz, o in zip(result, sizes, orig):

@@ -195,6 +195,40 @@ def test_conv_dual_source(ops, shape):
     assert float((got - two).abs().max()) <= 2e-5 * float(two.abs().max())
 
 
+@pytest.mark.parametrize("hw", [(64, 96), (70, 100)])
+def test_stem_space_to_depth(ops, hw):
+    """Space-to-depth form of the stem (preprocess -> [N,H/2,W/2,12], 4x4 / stride-1 conv with re-indexed weights, cropped
+    output grid) == the oracle's transform + 7x7 / stride-2 / pad-3 conv + FrozenBN + ReLU, and == the NHWC4 form."""
+    d = dev()
+    h, w = hw
+    from seam_match_rcnn_amd.models.detection import resized_size
+    clip = torch.from_numpy(synth.uniform(synth.stream_id(80, "clip"), (3, 3, h, w)))
+    imgs = list(clip.to(d).unbind(0))
+    ref_in, sizes = OD.transform(list(clip.unbind(0)), min_size=96, max_size=160)
+    hp, wp = ref_in.shape[-2:]
+    sz = [resized_size(h, w, 96, 160)[:2]] * 3
+    wt = rnd(81, (64, 3, 7, 7), "w") / (147 ** 0.5)
+    bnp = (torch.from_numpy(synth.uniform(synth.stream_id(82, "bw"), (64,), 0.5, 1.5)), rnd(83, (64,), "bb") * 0.1,
+           rnd(84, (64,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(85, "rv"), (64,), 0.5, 1.5)))
+    sc = bnp[0] * (bnp[3] + 1e-5).rsqrt()
+    ref = F.relu(F.conv2d(ref_in, wt, None, 2, 3) * sc[None, :, None, None] + (bnp[1] - bnp[2] * sc)[None, :, None, None])
+    x12 = ops.preprocess(imgs, sz, hp, wp, s2d=True)
+    assert x12.shape == (3, hp // 2, wp // 2, 12)
+    x4 = ops.preprocess(imgs, sz, hp, wp)
+    # layout: channel (dy*2+dx)*3 + c of cell (Y, X) = colour c of pixel (2Y+dy, 2X+dx)
+    back = x12.view(3, hp // 2, wp // 2, 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(3, hp, wp, 3)
+    assert torch.equal(back, x4[..., :3])
+    w8 = F.pad(wt, (1, 0, 1, 0))
+    ws = w8.view(64, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(64, 12, 4, 4).contiguous()
+    bn_d = tuple(t.to(d) for t in bnp)
+    pc12 = ops.pack_conv(ws.to(d), None, bn_d, stride=1, pad=2, cstore=12, wino=False)
+    got = ops.conv2d(x12, pc12, relu=True, out_hw=(hp // 2, wp // 2))
+    assert_close(got.permute(0, 3, 1, 2), ref)
+    pc4 = ops.pack_conv(wt.to(d), None, bn_d, stride=2, pad=3, cstore=4)
+    old = ops.conv2d(x4, pc4, relu=True)
+    assert old.shape == got.shape and float((old - got).abs().max()) <= 2e-5 * float(old.abs().max())
+
+
 def test_preprocess_batched_clip_tensor(ops):
     """The frames of one clip tensor (same-shape views at a constant stride) go through ONE launch; identical to the
     per-image launches."""
