@@ -80,7 +80,7 @@ class GeneralizedRCNNTransform(nn.Module):
         hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
         wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
         # exact-fp32 path with float images: space-to-depth layout for the 4x4 / stride-1 form of the stem (STEM_S2D)
-        s2d = STEM_S2D and adt(self) == torch.float32 and all(i.dtype == torch.float32 for i in images)
+        s2d = STEM_S2D and cdt(self) == torch.float32 and all(i.dtype == torch.float32 for i in images)
         return ops.preprocess(images, sizes, hp, wp, adt(self), s2d=s2d), sizes, orig, (hp, wp)
 
     @staticmethod

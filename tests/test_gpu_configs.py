@@ -100,10 +100,13 @@ def test_config5_shapes_fp32(ta):
     assert_close(att[5], atts[5][:, 0])
     img = torch.from_numpy(synth.frames(50, 1, 1080, 1920)[0])
     tr = GeneralizedRCNNTransform()
-    xb, sizes, orig = tr([img.to(dev())])
+    xb, sizes, orig, padded = tr([img.to(dev())])
     rb, rsz = OD.transform([img])
-    assert [tuple(z) for z in rsz] == [tuple(z) for z in sizes] and xb.shape[1:3] == rb.shape[-2:]
-    assert_close(xb[..., :3].permute(0, 3, 1, 2), rb, atol_scale=1e-5)
+    assert [tuple(z) for z in rsz] == [tuple(z) for z in sizes] and tuple(padded) == tuple(rb.shape[-2:])
+    # the exact-fp32 transform hands the stem a space-to-depth batch [N,H/2,W/2,12]: channel (dy*2+dx)*3 + c
+    assert xb.shape == (1, padded[0] // 2, padded[1] // 2, 12)
+    back = xb.view(1, padded[0] // 2, padded[1] // 2, 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(1, padded[0], padded[1], 3)
+    assert_close(back.permute(0, 3, 1, 2), rb, atol_scale=1e-5)
     sd = to_torch({k: v for k, v in synth.detector_state(5).items() if k.startswith("backbone.body.")})
     body = ResNet50Body()
     body.load_state_dict({k[len("backbone.body."):]: v for k, v in sd.items()})
