@@ -321,6 +321,17 @@ int seam_conv3x3_wino_f32(const float* x, const float* u_packed, const float* sc
                           seam_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * 1x1 convolutions / Linear layers with at most 16 outputs (csrc/seam_narrow.hip): y[M,K] = act(x[M,C] . w[K,C]^T + bias),
+ * C a multiple of 16, C <= 256, K <= 16 (seam_linear_narrow_supported).  Call sites: RPNHead.cls_logits + bbox_pred [TV]
+ * (3 + 12 outputs per pixel, packed as one [15, 256] weight) and MaskRCNNPredictor.mask_fcn_logits [TV] (14 classes).
+ * HBM-bound row stream on v_mfma_f32_16x16x4_f32 with the weights register-resident; w_packed = 64 * C floats from
+ * seam_pack_linear_narrow_f32 (source: the fp32 [K, C] weight). */
+int seam_linear_narrow_supported(int C, int K);
+int seam_pack_linear_narrow_f32(const float* w, float* w_packed, int K, int C, seam_stream_t stream);
+int seam_linear_narrow_f32(const float* x, const float* w_packed, const float* bias, float* y, long long M, int C, int K,
+                           int relu, seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Winograd F(2x4,3x3) convolution, fp32 MFMA (csrc/seam_wino24.hip): the same layers and the same contract as
  * seam_conv3x3_wino_f32, with output tiles of 2 rows x 4 columns (F(2,3) down the rows, F(4,3) with the points
  * {0, +-1, +-2, inf} along the columns): 24 multiplies per 8 outputs -- 3x fewer matrix-core issues than

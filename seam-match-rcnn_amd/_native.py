@@ -32,6 +32,9 @@ SIGNATURES = {
     "seam_conv_tile_prec": (_i, [_i, _i, _i]),
     "seam_pack_conv_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_linear_narrow_supported": (_i, [_i, _i]),
+    "seam_pack_linear_narrow_f32": (_i, [_p, _p, _i, _i, _p]),
+    "seam_linear_narrow_f32": (_i, [_p, _p, _p, _p, C.c_longlong, _i, _i, _i, _p]),
     "seam_conv2d_crop_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_s2d_batch_f32": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

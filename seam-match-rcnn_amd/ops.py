@@ -59,6 +59,7 @@ class PackedConv:
     dtype: object = F32             # operand precision of the packed weights: torch.float32 | torch.float16 | BX3
     u: Optional[torch.Tensor] = None  # fp32 stride-1 3x3 layers: Winograd F(2x2,3x3) weights (seam_pack_conv_weight_wino_f32)
     u24: Optional[torch.Tensor] = None  # ... and F(2x4,3x3) weights (seam_pack_conv_weight_wino24_f32)
+    wn: Optional[torch.Tensor] = None   # fp32 1x1 layers with <= 16 outputs: register-resident weights of seam_linear_narrow_f32
 
 
 BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
@@ -107,6 +108,8 @@ def _wino24_pays(lib, n, h, w, c, k, pad) -> bool:
     return f
 
 
+# <= 16-output 1x1 layers (RPN logits / deltas, mask logits) on the row-stream kernel of csrc/seam_narrow.hip (SEAM_NARROW=0: implicit GEMM)
+NARROW = _os.environ.get("SEAM_NARROW", "1") != "0"
 WINO_MIN_FILL = int(_os.environ.get("SEAM_WINO_MIN_FILL", "55"))    # % of tile slots in use below which the implicit GEMM wins
 _WINO_FILL = {}
 
@@ -185,7 +188,12 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         shift = shift.contiguous()
     elif bias is not None:
         shift = bias.contiguous()
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24)
+    wn = None
+    if (dtype == F32 and mode == 0 and R == 1 and S == 1 and stride == 1 and pad == 0 and scale is None and cs == cin
+            and lib.seam_linear_narrow_supported(cs, K)):
+        wn = torch.empty((64 * cs,), dtype=F32, device=weight.device)
+        _native.check(lib.seam_pack_linear_narrow_f32(_ptr(weight), _ptr(wn), K, cs, _stream()), "seam_pack_linear_narrow_f32")
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn)
 
 
 def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -> PackedConv:
@@ -342,9 +350,13 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = _native.lib()
+    narrow = pc.wn is not None and NARROW and residual is None and out_hw is None
     wino = pc.dtype == F32 and pc.u is not None and WINOGRAD and out_hw is None and _wino_pays(lib, n, h, w, c, pc.K, pc.pad)
     wino24 = wino and pc.u24 is not None and WINOGRAD24 and _wino24_pays(lib, n, h, w, c, pc.K, pc.pad)
-    if wino24:
+    if narrow:
+        _native.check(lib.seam_linear_narrow_f32(_ptr(x), _ptr(pc.wn), _ptr(pc.shift), _ptr(y), n * h * w, c, pc.K, int(relu), _stream()),
+                      "seam_linear_narrow_f32")
+    elif wino24:
         _native.check(lib.seam_conv3x3_wino24_f32(_ptr(x), _ptr(pc.u24), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                                   n, h, w, c, pc.K, pc.pad, int(relu), _stream()), "seam_conv3x3_wino24_f32")
     elif wino:
@@ -368,7 +380,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     if trace is not None:
         e1.record()
         tile = lib.seam_conv_tile_prec(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K)
-        if wino24:
+        if narrow:
+            variant = "linear_narrow"
+        elif wino24:
             variant = "conv3x3_wino24"
         elif wino:
             variant = f"conv3x3_wino<{lib.seam_wino_tile_variant(n, h, w, c, pc.K, pc.pad)}>"

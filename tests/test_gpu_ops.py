@@ -229,6 +229,31 @@ def test_stem_space_to_depth(ops, hw):
     assert old.shape == got.shape and float((old - got).abs().max()) <= 2e-5 * float(old.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(2, 23, 31, 256, 15), (1, 1, 1, 256, 14), (3, 7, 5, 64, 16), (1, 40, 33, 128, 3), (5000, 1, 1, 256, 14)])
+def test_linear_narrow(ops, shape):
+    """<= 16-output 1x1 layers (RPN logits + deltas, mask logits) on the row-stream kernel == torch, and == the implicit GEMM
+    within fp32 summation-order noise; ragged row counts (M not a multiple of 16)."""
+    d = dev()
+    n, h, w, c, k = shape
+    x = rnd(90, (n, c, h, w))
+    wt, b = rnd(91, (k, c, 1, 1), "w") / (c ** 0.5), rnd(92, (k,), "b")
+    pc = ops.pack_conv(wt.to(d), b.to(d))
+    assert pc.wn is not None
+    saved = ops.NARROW
+    try:
+        ops.NARROW = True
+        got = ops.conv2d(nhwc(x).to(d), pc, relu=(k == 16))
+        ops.NARROW = False
+        ref_gemm = ops.conv2d(nhwc(x).to(d), pc, relu=(k == 16))
+    finally:
+        ops.NARROW = saved
+    ref = F.conv2d(x, wt, b)
+    if k == 16:
+        ref = F.relu(ref)
+    assert_close(got.permute(0, 3, 1, 2), ref)
+    assert float((got - ref_gemm).abs().max()) <= 2e-5 * float(ref_gemm.abs().max())
+
+
 def test_preprocess_batched_clip_tensor(ops):
     """The frames of one clip tensor (same-shape views at a constant stride) go through ONE launch; identical to the
     per-image launches."""
