@@ -63,9 +63,29 @@ struct ConvArgs {
     // bn_d(conv_d(x)) as ONE GEMM (scales folded into the weights), so the shortcut never goes to memory and back.
     const void* x2;
     int H2, W2, C2, stride2;
+    // Row -> (image, ho, wo) without integer divisions (each costs ~20 VALU instructions, per row, per tile -- and VALU
+    // instructions delay the matrix pipe): m_HoWo / m_Wo = ceil(2^32 / d), valid for the operand ranges of split_row() when
+    // div_fast is set (Ho*Wo*Wo < 2^32; the host checks).  A tile's rows are first made local to its first image.
+    unsigned m_HoWo, m_Wo;
+    int div_fast;
     int rH, rW;        // > 0 (fp32, K % 4 == 0 only): `res` is a coarser map [N, rH, rW, K] added through a nearest-neighbour
                        // upsample to [Ho, Wo] (ATen: src = min(floor(dst * rH / Ho), rH - 1)) -- the FPN top-down merge
 };
+
+// rl = row index local to the tile's first image (0 <= rl < Ho*Wo + tile rows) -> images past that one, ho, wo
+__device__ __forceinline__ void split_row(const ConvArgs& p, int HoWo, int rl, int& nl, int& ho, int& wo) {
+    if (p.div_fast) {
+        nl = HoWo >= 256 ? (rl >= HoWo ? 1 : 0) : (HoWo == 1 ? rl : (int)__umulhi((unsigned)rl, p.m_HoWo));
+        const int rm = rl - nl * HoWo;
+        ho = p.Wo == 1 ? rm : (int)__umulhi((unsigned)rm, p.m_Wo);
+        wo = rm - ho * p.Wo;
+    } else {
+        nl = rl / HoWo;
+        const int rm = rl - nl * HoWo;
+        ho = rm / p.Wo;
+        wo = rm - ho * p.Wo;
+    }
+}
 
 template <typename T, int BM, int BN, int NW, bool DUAL = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const ConvArgs p) {
@@ -138,34 +158,37 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const int m = m0 + lrow + RP * i;
-                const int n = m / HoWo;
-                const int rm = m - n * HoWo;
-                const int ho = rm / p.Wo;
-                const int wo = rm - ho * p.Wo;
+                const int rl = m - n_first * HoWo;
+                int nl, ho, wo;
+                split_row(p, HoWo, rl, nl, ho, wo);
                 const bool ok = m < p.M;
-                arow1[i] = ok ? (unsigned)(((((n - n_first) * p.Ho + ho) * p.Wo + wo) * p.C) * ES + lcol * 16) : kOob;
-                arow2[i] = ok ? (unsigned)(((((n - n_first) * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.C2) * ES + lcol * 16) : kOob;
+                arow1[i] = ok ? (unsigned)(rl * p.C * ES + lcol * 16) : kOob;      // source 1 is the output grid itself
+                arow2[i] = ok ? (unsigned)((((nl * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.C2) * ES + lcol * 16) : kOob;
             }
         }
         const int n_in_slab = n0 % p.slab_bn;
         b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)((const char*)p.w + (size_t)(n0 - n_in_slab) * p.kred * ES + (size_t)n_in_slab * CHUNK_BYTES), 0,
             (int)((unsigned)nk * (unsigned)slab_stride), 0x00020000);
+        const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;       // input pixel = output pixel: no split at all
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int m = m0 + lrow + RP * i;
-            if (m < p.M) {
-                const int n = m / HoWo;
-                const int rm = m - n * HoWo;
-                const int ho = rm / p.Wo;
-                const int wo = rm - ho * p.Wo;
-                ahi[i] = ho * p.stride - p.pad;
-                awi[i] = wo * p.stride - p.pad;
-                arow[i] = ((((n - n_first) * p.H + ahi[i]) * p.W + awi[i]) * p.C) * ES;
-            } else {
+            const int rl = m - n_first * HoWo;
+            if (DUAL || m >= p.M) {
                 ahi[i] = -(1 << 28);
                 awi[i] = 0;
                 arow[i] = 0;
+            } else if (pointwise) {
+                ahi[i] = 0;
+                awi[i] = 0;
+                arow[i] = rl * p.C * ES;
+            } else {
+                int nl, ho, wo;
+                split_row(p, HoWo, rl, nl, ho, wo);
+                ahi[i] = ho * p.stride - p.pad;
+                awi[i] = wo * p.stride - p.pad;
+                arow[i] = (((nl * p.H + ahi[i]) * p.W + awi[i]) * p.C) * ES;
             }
         }
         // (r, s, c) of this thread's 16-byte vector inside the chunk being fetched, and its byte offset.
@@ -396,13 +419,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         const int m = cm0 + wm0 + i * 32 + k * RPI + er;
-                        const int img = m / HoWo;
-                        const int rm = m - img * HoWo;
-                        const int ho = rm / p.Wo;
-                        const int wo = rm - ho * p.Wo;
+                        int nl, ho, wo;
+                        split_row(p, HoWo, m - up_first * HoWo, nl, ho, wo);
                         const int ht = min((int)floorf((float)ho * shs), p.rH - 1);
                         const int wt = min((int)floorf((float)wo * sws), p.rW - 1);
-                        const unsigned uo = (nok && m < p.M) ? (unsigned)((((img - up_first) * p.rH + ht) * p.rW + wt) * p.K + n) * 4u : kOob;
+                        const unsigned uo = (nok && m < p.M) ? (unsigned)(((nl * p.rH + ht) * p.rW + wt) * p.K + n) * 4u : kOob;
                         rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uo, 0, 0));
                     }
                 } else if (p.res) {
@@ -887,6 +908,16 @@ inline void choose_tile(int prec, int M, int K, int& best_bm, int& best_bn) {
 
 struct DualSrc { const void* x2; int H2, W2, C2, stride2; };
 
+// multipliers of split_row(): exact while the operand times the divisor stays below 2^32 -- rl < Ho*Wo + 256 against Ho*Wo (used
+// only when Ho*Wo < 256), rm < Ho*Wo against Wo
+inline void set_row_split(ConvArgs& a) {
+    const unsigned long long howo = (unsigned long long)a.Ho * a.Wo;
+    auto magic = [](unsigned long long d) -> unsigned { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
+    a.m_HoWo = magic(howo);
+    a.m_Wo = magic((unsigned long long)a.Wo);
+    a.div_fast = (a.Ho > 0 && a.Wo > 0 && howo * (unsigned long long)a.Wo < (1ull << 32)) ? 1 : 0;
+}
+
 template <typename T>
 int conv2d(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int relu, int y_f32, void* stream,
@@ -909,6 +940,7 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.y_f32 = y_f32;
     a.rH = rH; a.rW = rW;
     a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
+    set_row_split(a);
     if (dual) {
         if (sizeof(T) != 4 || R != 1 || S != 1 || stride != 1 || pad != 0 || (C % BKE) || (dual->C2 % BKE) || dual->stride2 < 1 ||
             (a.Ho - 1) * dual->stride2 >= dual->H2 || (a.Wo - 1) * dual->stride2 >= dual->W2 || !dual->x2)
@@ -965,6 +997,7 @@ int conv2d_bx3(const void* x, const void* w_packed, const float* scale, const fl
     a.y_f32 = 1;
     a.rH = 0; a.rW = 0;
     a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
+    set_row_split(a);
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
     const int rows = ((K + 63) / 64) * 64;
     a.slab_bn = rows % 128 == 0 ? 128 : 64;
