@@ -169,3 +169,34 @@ assert worst < 2e-5, worst
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_full_size_layers_against_the_exact_kernel(ops):
+    """BASELINE-size layers (one clip's 10 frames at 200^2 x 256 channels) through the kernels the bench uses -- F(2x4)
+    Winograd for the 3x3, the row-stream kernel for the 15 RPN outputs -- against the exact implicit GEMM on the same inputs
+    (size-independent property: both are the same linear map; max deviation in units of the output scale), plus linearity."""
+    d = torch.device("cuda:0")
+    n, h, w, c = 10, 200, 200, 256
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn((n, h, w, c), generator=g).abs_().to(d)                   # ReLU-like activations
+    wt = (torch.randn((256, c, 3, 3), generator=g) / math.sqrt(9 * c)).to(d)
+    pc = ops.pack_conv(wt, torch.zeros(256, device=d), stride=1, pad=1)
+    saved = ops.WINOGRAD, ops.WINOGRAD24, ops.NARROW
+    try:
+        ops.WINOGRAD, ops.WINOGRAD24 = True, 2
+        y24 = ops.conv2d(x, pc, False)
+        y24_2x = ops.conv2d(2.0 * x, pc, False)
+        ops.WINOGRAD = False
+        yd = ops.conv2d(x, pc, False)
+        scale = float(yd.abs().max())
+        assert float((y24 - yd).abs().max()) <= 2e-5 * scale
+        assert torch.equal(y24_2x, 2.0 * y24)                                  # scaling by a power of two is exact in every form
+        wl = (torch.randn((15, c, 1, 1), generator=g) / math.sqrt(c)).to(d)
+        pl = ops.pack_conv(wl, torch.randn(15, generator=g).to(d))
+        ops.NARROW = True
+        a = ops.conv2d(y24, pl)
+        ops.NARROW = False
+        b = ops.conv2d(y24, pl)
+        assert a.shape == (n, h, w, 15) and float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    finally:
+        ops.WINOGRAD, ops.WINOGRAD24, ops.NARROW = saved
