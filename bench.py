@@ -2,7 +2,7 @@
 """bench.py -- video-clips/sec of the SEAM Match-RCNN forward hot path on MI355X.
 
 Metric (BASELINE.json): video-clips/sec, clip = 10 frames x 800x800, 32 fixed ROIs/frame,
-1000-product gallery (configs[1]).  One *step* = one clip per rank through the whole path
+1000-product gallery (configs[1]).  One *step* = ``--clips`` (8) clips per rank through the whole path
 with fixed ROIs (SURVEY.md 8d "full pipeline with fixed ROIs", 3.07 TFLOP/clip):
 
   frames[10,3,800,800] (resident in HBM) -> normalise/pad -> ResNet-50 body -> FPN -> RPN head
@@ -10,13 +10,25 @@ with fixed ROIs (SURVEY.md 8d "full pipeline with fixed ROIs", 3.07 TFLOP/clip):
   (match_features) -> temporal_aggregator Mode A: trunk + 32 sequences x 10 through the non-local
   block + attention pooling -> pairwise match logits vs the 1000-product bank -> top-20.
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); every rank runs its own
-clip per step (weak scaling) and *owns* 1000/N rows of the product bank, which are all-gathered
-on a side stream each step before the match.  Rank 0 prints ONE JSON line.
+Workloads (``--workload``): c2 = configs[1] (the metric's config, default) | c3 = configs[2] (8 clips per step, 20 000-product
+gallery, ranking without the [S,G,2] logits in HBM) | c4 = configs[3] per-rank view (8 clips per rank per step, 50 000-product bank
+whose shards are all-gathered over RCCL every step) | c5 = configs[4] per-GPU shape (30 x 1080p frames, 64 ROI/frame; --dtype f16).
 
-Extra legs (rank 0, N == 1 only): `roofline` for the dominant kernel (conv_igemm<float,128,128>,
-bound = fp32 MFMA) from HIP events bracketing every launch of one instrumented step, and
-`cpu_baseline` = the CPU oracle timed on the host cores for one clip.
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); every rank runs its own clips per step (weak scaling)
+and *owns* G/N rows of the product bank, which are all-gathered on a side stream each step before the match (the achieved
+all-gather rate per xGMI link is reported under ``allgather``).  Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N == 1 only):
+  roofline      the dominant kernel of one instrumented step (HIP events bracketing every conv launch on the launch stream);
+                ``achieved`` = MFMA FLOP/s the kernel ISSUES for its algorithmic work (algorithmic / 3 for Winograd F(2x4,3x3),
+                / 2.25 for F(2x2,3x3)), ``frac`` = achieved / the dense MFMA peak of the dtype (always <= 1); the
+                direct-convolution-equivalent rate is kept as ``algorithmic_tflops``.
+  cpu_baseline  the CPU oracle (torch-CPU restatement) on the host cores for one clip: 1 warm-up, min of ``--cpu-runs`` (3).
+  parity        the timed GPU step's outputs for clip 0 (roi_features, x3_1b, match logits, top-20) against the outputs the
+                cpu_baseline leg computed from the same inputs; the run FAILS when they disagree by more than 1e-3.
+  extras        ``value_clips1`` (one clip per step) and ``full_forward_ms_per_clip`` (the drop-in ``model(images)`` forward
+                with RPN proposals, box head, NMS and mask paste on the same 10 frames).  ``--no-extras`` skips them (used for
+                the rocprofv3 kernel-stats run, so that the per-kernel averages cover the 8-clip steps only).
 """
 import argparse
 import json
@@ -29,11 +41,17 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 F16_MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak (not the 2:1-sparse marketing figure)
-T, R, G, TOPK = 10, 32, 1000, 20
-H = W = 800
-# algorithmic FLOP per clip: 10 frames x 240.0 G + 320 ROIs x (2 trunks + mask head)
-FLOP_PER_CLIP = 10 * 240.0e9 + 320 * (2 * 0.5338e9 + 1.033e9)
-
+XGMI_LINK_GBS = 153.0                  # per-link, per-direction (MI355X_MICROARCH.md / BASELINE.md section 2)
+TOPK = 20
+WORKLOADS = {
+    # name: frames, ROI/frame, H, W, gallery, BASELINE.json config it stands for, how the match is ranked
+    "c2": dict(T=10, R=32, H=800, W=800, G=1000, cfg="configs[1]", rank="logits"),
+    "c3": dict(T=10, R=32, H=800, W=800, G=20000, cfg="configs[2]", rank="topk"),
+    "c4": dict(T=10, R=32, H=800, W=800, G=50000, cfg="configs[3] per-rank view (64 clips over 8 GPUs = 8 clips per rank per step)",
+               rank="topk"),
+    "c5": dict(T=30, R=64, H=1080, W=1920, G=1000, cfg="configs[4] per-GPU shape", rank="logits"),
+}
+PARITY_TOL = 1e-3                      # north_star: within 1e-3 relative fp32 (16-bit paths: reported, looser gate)
 
 _T0 = time.perf_counter()
 
@@ -50,19 +68,22 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=T, help="frames of the clip the CPU baseline times")
+    ap.add_argument("--no-extras", action="store_true", help="skip the value_clips1 / full_forward_ms_per_clip legs")
+    ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the clip the CPU baseline times (default: all)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU runs after one warm-up; the minimum is reported")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph (torch.cuda.CUDAGraph) and time graph replays")
-    ap.add_argument("--workload", choices=("c2", "c5"), default="c2",
-                    help="c2 (default, the BASELINE metric's config): 10 x 800x800 frames, 32 ROI/frame, fp32; "
+    ap.add_argument("--workload", choices=tuple(WORKLOADS), default="c2",
+                    help="c2 (default, the BASELINE metric's config): 10 x 800x800 frames, 32 ROI/frame, 1000 products, fp32; "
+                         "c3: configs[2], 20 000 products; c4: configs[3] per-rank view, 50 000 products all-gathered per step; "
                          "c5: configs[4] per-GPU shape -- 30 x 1080x1920 frames, 64 ROI/frame (use with --dtype f16)")
     ap.add_argument("--clips", type=int, default=8,
-                    help="clips batched per step on each GPU: their 10 x clips frames go through the extractor as one batch "
+                    help="clips batched per step on each GPU: their frames go through the extractor as one batch "
                          "(BASELINE configs[2] batches 8 clips the same way); value counts clips/s.  --clips 1 = one clip "
-                         "per step (latency-oriented; 11 % lower throughput: the small pyramid levels cannot fill 256 CUs)")
+                         "per step (latency-oriented; ~11 %% lower throughput: the small pyramid levels cannot fill 256 CUs)")
     ap.add_argument("--dtype", choices=("f32", "f16", "bf16x3"), default="f32",
                     help="f32 (default, the headline: exact fp32 MFMA) | f16 (config-5 style fp16 MFMA, fp32 accumulate; "
-                         "extractor + trunks in fp16, descriptors / NLB / match logits fp32)")
+                         "extractor + trunks in fp16, descriptors / NLB / match logits fp32) | bf16x3 (split-bf16, opt-in)")
     return ap.parse_args()
 
 
@@ -77,14 +98,17 @@ def build_model(dev):
     return model.to(dev).eval(), sd
 
 
+def flop_per_clip(wl):
+    """Algorithmic FLOP per clip: frames x (body + FPN + RPN head) + ROIs x (2 trunks + mask head)."""
+    per_frame = 240.0e9 if (wl["H"], wl["W"]) == (800, 800) else 387.1e9      # 1080p -> 749x1333 -> padded 768x1344
+    return wl["T"] * per_frame + wl["T"] * wl["R"] * (2 * 0.5338e9 + 1.033e9)
+
+
 def main():
     args = parse()
-    global T, R, H, W, FLOP_PER_CLIP
-    if args.workload == "c5":
-        T, R, H, W = 30, 64, 1080, 1920
-        # 1080p -> 749x1333 -> padded 768x1344: 387.1 GFLOP/frame
-        FLOP_PER_CLIP = T * 387.1e9 + T * R * (2 * 0.5338e9 + 1.033e9)
-    import numpy as np
+    wl = WORKLOADS[args.workload]
+    T, R, H, W, G = wl["T"], wl["R"], wl["H"], wl["W"], wl["G"]
+    FLOP_PER_CLIP = flop_per_clip(wl)
     import torch
     import torch.distributed as dist
     import seam_match_rcnn_amd.synth as synth
@@ -121,16 +145,29 @@ def main():
     types = torch.zeros(B * T * R, dtype=torch.int32)                        # all street ROIs (CPU, as the ref passes)
     ids = torch.cat([c * R + torch.arange(R, dtype=torch.int64).repeat(T) for c in range(B)])   # sequence id = (clip, ROI slot)
     lo, hi = retrieval.shard_range(G, rank, world)
-    bank_shard = torch.from_numpy(synth.gallery(7, G)[lo:hi]).to(dev)        # this rank's product descriptors
+    bank_shard = torch.from_numpy(synth.gallery(7, G)[lo:hi]).to(dev)        # this rank's rows of the product-descriptor bank
     side = torch.cuda.Stream(device=dev) if world > 1 else None
+    gathers = []                                                             # timed all-gathers of the measured steps
+
+    def run_step(flist, rlist, ty, sid, timed_gather=False):
+        pending = retrieval.gather_product_bank(bank_shard, G, side_stream=side, timed=timed_gather)   # overlaps the extractor
+        if timed_gather and pending.events is not None:
+            gathers.append(pending)
+        res, feats, rpn = model.forward_fixed_rois(flist, rlist, run_rpn_head=True)
+        roi_features = ops.cat_rows([r["roi_features"] for r in res])       # [K,256,14,14] (the per-image views, re-joined)
+        out = ta(roi_features, ty, sid)                                      # Mode A: trunk + NLB + attention pool
+        bank = pending.wait()
+        if wl["rank"] == "logits":
+            x5, idx, score = retrieval.match_sequences(ta, out[0], bank, TOPK)
+        else:                                                                # configs 3/4: no [S,G,2] logits in HBM
+            x5 = None
+            idx, score = retrieval.match_sequences_topk(ta, out[0], bank, TOPK)
+        return res, out, x5, idx, score, bank
+
+    state = {"timed": False}
 
     def step():
-        pending = retrieval.gather_product_bank(bank_shard, G, side_stream=side)   # overlaps the extractor
-        res, feats, rpn = model.forward_fixed_rois(frame_list, rois, run_rpn_head=True)
-        roi_features = torch.cat([r["roi_features"] for r in res])          # [320,256,14,14] (reference layout)
-        out = ta(roi_features, types, ids)                                    # Mode A: trunk + NLB + attention pool
-        x5, idx, score = retrieval.match_sequences(ta, out[0], pending.wait(), TOPK)
-        return res, out, x5, idx, score
+        return run_step(frame_list, rois, types, ids, timed_gather=state["timed"])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -152,6 +189,7 @@ def main():
             graph_out = step()
         run = graph.replay
     log("warmup")
+    last = None
     with torch.no_grad():
         for _ in range(args.warmup):
             run()
@@ -159,11 +197,15 @@ def main():
             log("warmup step done")
         sync_all()
         log("timing")
+        state["timed"] = world > 1 and not args.graph
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            run()
+            last = run()
         sync_all()
         elapsed = time.perf_counter() - t0
+        state["timed"] = False
+    if args.graph:
+        last = graph_out
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -173,101 +215,195 @@ def main():
     log(f"timed: {ms_per_step:.2f} ms/step")
     value = world * B * args.steps / elapsed                                  # whole-job clips/s
 
+    allgather = None
+    if world > 1 and gathers:
+        us = sorted(g.elapsed_us() for g in gathers)
+        med = us[len(us) // 2]
+        tt = torch.tensor([med], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)                              # slowest rank's median
+        med = float(tt.item())
+        shard_bytes = (retrieval.shard_range(G, 0, world)[1]) * 256 * 4       # what a rank sends to EACH peer
+        allgather = {"collective": "all_gather_into_tensor (RCCL over xGMI), side stream, overlapped with the extractor",
+                     "bytes_sent_per_peer": shard_bytes, "bytes_received_per_rank": (world - 1) * shard_bytes,
+                     "median_us_slowest_rank": round(med, 1),
+                     "GB/s_per_link_if_direct": round(shard_bytes / med / 1e3, 2),
+                     "GB/s_received_per_rank": round((world - 1) * shard_bytes / med / 1e3, 2),
+                     "xgmi_link_peak_GB/s": XGMI_LINK_GBS,
+                     "bound_us_direct_full_mesh": round(shard_bytes / XGMI_LINK_GBS / 1e3, 1),
+                     "bound_us_ring": round((world - 1) * shard_bytes / XGMI_LINK_GBS / 1e3, 1),
+                     "note": "device time of the collective between HIP events on its stream; it runs concurrently with the "
+                             "extractor's kernels, so this is an upper bound on its isolated duration"}
+
     roofline = None
     if rank == 0 and world == 1 and not args.no_roofline:
-        with torch.no_grad():
-            ops.CONV_TRACE = []
-            step()
-            torch.cuda.synchronize()
-            trace, ops.CONV_TRACE = ops.CONV_TRACE, None
-        per = {}
-        for variant, flops, e0, e1, _shape, nbytes in trace:
-            a = per.setdefault(variant, [0, 0.0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += e0.elapsed_time(e1) * 1e-3
-            a[3] += nbytes
-        dom = max(per, key=lambda k: per[k][2])
-        n, fl, sec, alg_bytes = per[dom]
-        achieved = fl / sec / 1e12
-        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else F16_MFMA_PEAK_TFLOPS
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    **({"mfma_passes_per_product": 3, "issued_frac": round(3 * achieved / peak, 4)} if args.dtype == "bf16x3" else {}),
-                    **({"algorithm": "Winograd F(2x4,3x3): 24 MFMA multiplies per 2x4 output tile and channel pair instead of 72, "
-                                     "so `achieved` (ALGORITHMIC FLOP/s, 2*M*K*9*C per launch) can exceed the MFMA peak",
-                        "mfma_issued_frac": round(achieved / 3.0 / peak, 4)} if dom == "conv3x3_wino24" else
-                       {"algorithm": "Winograd F(2x2,3x3): 16 MFMA multiplies per 2x2 output tile and channel pair instead of 36, "
-                                     "so `achieved` (ALGORITHMIC FLOP/s, 2*M*K*9*C per launch) can exceed the MFMA peak",
-                        "mfma_issued_frac": round(achieved / 2.25 / peak, 4)} if dom.startswith("conv3x3_wino") else {}),
-                    "traffic": pmc_traffic(dom) if args.dtype == "f32" else None,
-                    "mfma_busy_frac_pmc": pmc_mfma_busy(dom) if args.dtype == "f32" else None,
-                    "algorithmic_bytes_per_launch": round(alg_bytes / n),
-                    "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
-                    "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
-                    "conv_ms_per_step": round(1e3 * sum(v[2] for v in per.values()), 3),
-                    "other_variants": {k: {"launches": v[0], "TFLOP/s": round(v[1] / v[2] / 1e12, 2)}
-                                       for k, v in per.items() if k != dom}}
+        roofline = roofline_leg(step, args.dtype)
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "c2":
+    cpu = cpu_out = None
+    n_cpu = args.cpu_frames if args.cpu_frames is not None else T
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and (args.workload != "c5" or args.cpu_frames is not None)
+    if want_cpu:
         log("cpu baseline")
-        cpu = cpu_baseline(sd, frames[:T].cpu(), rois_np, args.cpu_frames)
+        cpu, cpu_out = cpu_baseline(sd, frames[:T].cpu(), rois_np, n_cpu, wl, max(1, args.cpu_runs))
         log("cpu baseline done")
 
+    parity = None
+    if cpu_out is not None:
+        parity = parity_leg(last, cpu_out, wl, n_cpu, ta, args.dtype)
+        log(f"parity: {parity}")
+
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2" and not args.graph:
+        log("extras: one clip per step, full drop-in forward")
+        with torch.no_grad():
+            n1 = T * R
+            ids1 = torch.arange(R, dtype=torch.int64).repeat(T)
+            one = lambda: run_step(frame_list[:T], rois[:T], types[:n1], ids1)   # noqa: E731
+            for _ in range(2):
+                one()
+            torch.cuda.synchronize()
+            k1 = max(5, args.steps)
+            t0 = time.perf_counter()
+            for _ in range(k1):
+                one()
+            torch.cuda.synchronize()
+            extras["value_clips1"] = round(k1 / (time.perf_counter() - t0), 4)
+            ts = []
+            for i in range(4):                                                # drop-in model(images): RPN + box head + NMS + paste
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                det = model(frame_list[:T])
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            extras["full_forward_ms_per_clip"] = round(1e3 * sorted(ts[1:])[1], 3)
+            extras["full_forward_detections_per_frame"] = [int(len(d["scores"])) for d in det]
+            extras["extras_note"] = ("value_clips1: the same step with ONE clip per step (latency-oriented); "
+                                     "full_forward_ms_per_clip: median of 3 of model(10 frames) with RPN proposals, box head, "
+                                     "per-class NMS, mask + match branches and mask paste (not part of `value`)")
+
+    failed = None
     if rank == 0:
-        metric = ("video-clips/sec (10f x 800^2, 32 ROI/f, 1k gallery)" if args.workload == "c2"
+        what = (f"{wl['cfg']} full pipeline, fixed ROIs: {T} frames {H}x{W} -> ResNet-50-FPN + RPN head "
+                f"-> RoIAlign 14x14 ({R} ROI/frame) -> mask head -> match trunk x2 -> SEAM NLB + "
+                f"attention pool ({R} seq x {T}) -> " +
+                (f"pair logits vs {G}-product bank -> top-{TOPK}" if wl["rank"] == "logits" else
+                 f"pair logits + top-{TOPK} vs {G}-product bank in query chunks (no [S,G,2] tensor in HBM)"))
+        gal = {1000: "1k", 20000: "20k", 50000: "50k"}[G]
+        metric = (f"video-clips/sec (10f x 800^2, 32 ROI/f, {gal} gallery)" if args.workload != "c5"
                   else "video-clips/sec (30f x 1080p, 64 ROI/f, 1k gallery)")
         line = {"metric": metric, "value": round(value, 4),
                 "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": ("configs[1]" if args.workload == "c2" else "configs[4] per-GPU shape") +
-                                       f" full pipeline, fixed ROIs: {T} frames {H}x{W} -> ResNet-50-FPN + RPN head "
-                                       f"-> RoIAlign 14x14 ({R} ROI/frame) -> mask head -> match trunk x2 -> SEAM NLB + "
-                                       f"attention pool ({R} seq x {T}) -> pair logits vs {G}-product bank -> top-{TOPK}",
+                "config": {"workload": what,
                            "clips_per_step_per_gpu": B, "hip_graph": bool(args.graph), "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
                            "algorithmic_tflop_per_clip": round(FLOP_PER_CLIP / 1e12, 3),
                            "parallelism": f"dp{world} (clips sharded; product bank all-gathered over RCCL)"
                            if world > 1 else "single GPU"},
                 "pipeline_tflops": round(FLOP_PER_CLIP * value / 1e12, 2)}
+        line.update(extras)
+        if allgather is not None:
+            line["allgather"] = allgather
         if roofline is not None:
             line["roofline"] = roofline
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if parity is not None:
+            line["parity"] = parity
+            if not parity["ok"]:
+                failed = f"parity outside tolerance: {parity}"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: " + failed)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
-    produced by tools/pmc_bench_traffic.sh on this same bench command): FETCH_SIZE and WRITE_SIZE are
-    collected in separate passes, reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
-    coalesced reads, so the read side is doubled (MI355X_MICROARCH.md, HBM section).  None when absent."""
+# ------------------------------------------------------------------------------------------------ roofline
+def roofline_leg(step, dtype):
+    """One instrumented step: every conv launch bracketed by HIP events on its launch stream (ops.CONV_TRACE)."""
+    import torch
+    from seam_match_rcnn_amd import ops
+    with torch.no_grad():
+        ops.CONV_TRACE = []
+        step()
+        torch.cuda.synchronize()
+        trace, ops.CONV_TRACE = ops.CONV_TRACE, None
+    per = {}
+    for variant, flops, e0, e1, _shape, nbytes in trace:
+        a = per.setdefault(variant, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+        a[3] += nbytes
+    dom = max(per, key=lambda k: per[k][2])
+    n, fl, sec, alg_bytes = per[dom]
+    algorithmic = fl / sec / 1e12
+    peak = FP32_MFMA_PEAK_TFLOPS if dtype == "f32" else F16_MFMA_PEAK_TFLOPS
+    # MFMA multiplies issued per algorithmic multiply-accumulate of the direct convolution
+    if dom.startswith("conv3x3_wino24"):
+        issue, algo = 1.0 / 3.0, "Winograd F(2x4,3x3): 24 MFMA multiplies per 2x4 output tile and channel pair instead of 72"
+    elif dom.startswith("conv3x3_wino"):
+        issue, algo = 1.0 / 2.25, "Winograd F(2x2,3x3): 16 MFMA multiplies per 2x2 output tile and channel pair instead of 36"
+    elif dom.startswith("conv_igemm_bx3"):
+        issue, algo = 3.0, "split-bf16: 3 bf16 MFMAs per fp32 product (hi*hi + hi*lo + lo*hi)"
+    else:
+        issue, algo = 1.0, "implicit GEMM: one MFMA multiply per algorithmic multiply"
+    achieved = algorithmic * issue
+    src, traffic, busy = pmc_fields(dom) if dtype == "f32" else (None, None, None)
+
+    def rate(v):
+        return round(v[1] / v[2] / 1e12, 2)
+
+    return {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "achieved_is": "MFMA FLOP/s issued for the algorithmic work = algorithmic_tflops x mfma_issue_ratio "
+                           "(unfilled tile slots are not counted as work)",
+            "algorithm": algo, "mfma_issue_ratio": round(issue, 4),
+            "algorithmic_tflops": round(algorithmic, 2),
+            "algorithmic_flops_are": "2*M*K*R*S*C of the direct convolution per launch (SURVEY.md 8d)",
+            "traffic": traffic, "mfma_busy_frac_pmc": busy,
+            "pmc_source": src,
+            "algorithmic_bytes_per_launch": round(alg_bytes / n),
+            "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
+            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+            "conv_ms_per_step": round(1e3 * sum(v[2] for v in per.values()), 3),
+            "other_variants": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[2], 3), "algorithmic_TFLOP/s": rate(v)}
+                               for k, v in per.items() if k != dom}}
+
+
+def pmc_fields(kernel):
+    """(source, traffic, mfma_busy) of `kernel` from the newest COMMITTED rocprofv3 PMC passes (profiles/*_pmc_traffic.json, made
+    by tools/pmc_bench_traffic.sh over this same bench command on an earlier run -- NOT measured in this process; `source`
+    names the file so that a reader can tell).  traffic = HBM-side bytes per launch: FETCH_SIZE and WRITE_SIZE are collected in
+    separate passes and reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads, so the read
+    side is doubled (MI355X_MICROARCH.md, HBM section).  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None, None
+    traffic = busy = None
     try:
         d = json.load(open(files[-1]))
-        return round((2.0 * d["FETCH_SIZE"][kernel]["avg_per_launch"] + d["WRITE_SIZE"][kernel]["avg_per_launch"]) * 1024)
-    except (KeyError, ValueError, OSError):
-        return None
-
-
-def pmc_mfma_busy(kernel):
-    """Matrix-pipe busy fraction of `kernel` from the same committed PMC passes:
-    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES).  None when absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    except (ValueError, OSError):
+        return None, None, None
     try:
-        return json.load(open(files[-1]))["mfma_busy_frac"][kernel]
-    except (IndexError, KeyError, ValueError, OSError):
-        return None
+        traffic = round((2.0 * d["FETCH_SIZE"][kernel]["avg_per_launch"] + d["WRITE_SIZE"][kernel]["avg_per_launch"]) * 1024)
+    except KeyError:
+        pass
+    try:
+        busy = d["mfma_busy_frac"][kernel]
+    except KeyError:
+        pass
+    src = {"file": os.path.relpath(files[-1], ROOT), "measured_in_this_run": False,
+           "how": "tools/pmc_bench_traffic.sh: separate rocprofv3 --pmc passes over `bench.py --steps 2 --warmup 1`; "
+                  "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per launch"}
+    if isinstance(d.get("_meta"), dict):
+        src.update(d["_meta"])
+    return src, traffic, busy
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline + parity
 def usable_cores():
     """Host cores this process may actually use: min(affinity, cgroup cpu.max quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -280,15 +416,27 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(sd, frames_cpu, rois_np, n_frames):
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.lower().startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(sd, frames_cpu, rois_np, n_frames, wl, runs):
     """The CPU oracle (kind = "port": torch-CPU restatement, the same ATen kernels the reference
-    dispatches) timed on the host cores for ONE clip (bounded sample), frame by frame."""
+    dispatches) timed on the host cores for ONE clip (bounded sample), frame by frame: 1 warm-up run, then the
+    minimum of `runs` timed runs.  Also returns the outputs of the last run (the parity leg's reference)."""
     import torch
     from oracle import detection as OD
     from oracle import heads as OH
     from oracle import model as OM
     import seam_match_rcnn_amd.synth as synth
 
+    T, R, G = wl["T"], wl["R"], wl["G"]
     cores = usable_cores()
     torch.set_num_threads(cores)
     rois = torch.from_numpy(rois_np)
@@ -296,8 +444,8 @@ def cpu_baseline(sd, frames_cpu, rois_np, n_frames):
     mp = OM.sub(sd, "roi_heads.match_predictor.")
     tap = OM.sub(sd, "roi_heads.temporal_aggregator.")
     bank = torch.from_numpy(synth.gallery(7, G))
-    with torch.no_grad():
-        t0 = time.perf_counter()
+
+    def one_clip():
         roi_feats = []
         for f in range(n_frames):
             batch, sizes = OD.transform([frames_cpu[f]])
@@ -310,13 +458,62 @@ def cpu_baseline(sd, frames_cpu, rois_np, n_frames):
         x = torch.cat(roi_feats)
         ids = torch.arange(R, dtype=torch.int64).repeat(n_frames)
         out = OH.temporal_aggregation_forward(x, torch.zeros(len(ids), dtype=torch.int32), ids, tap)
-        x5 = OH.pair_logits(out[0], bank, tap["last.weight"], tap["last.bias"])
-        OH.rank_topk(x5, TOPK)
-        sec = time.perf_counter() - t0
+        x5 = OH.pair_logits(out[0], bank, tap["last.weight"], tap["last.bias"], chunk=8 if G > 4096 else 64)
+        idx, score = OH.rank_topk(x5, TOPK)
+        return dict(roi_features=x, x3_1b=out[0], x5=x5, idx=idx, score=score)
+
+    secs = []
+    with torch.no_grad():
+        for i in range(1 + runs):                      # run 0 = warm-up (page-in, oneDNN primitive caches)
+            t0 = time.perf_counter()
+            outs = one_clip()
+            secs.append(time.perf_counter() - t0)
+    sec = min(secs[1:])
     clip_sec = sec * (T / n_frames)      # per-frame work dominates; scale when fewer frames were timed
-    return {"value": round(1.0 / clip_sec, 5), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"1 clip, {n_frames} of {T} frames timed ({sec:.1f} s), same stages/inputs as the GPU step; "
-                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+    return ({"value": round(1.0 / clip_sec, 5), "unit": "clips/s", "cores": cores, "kind": "port",
+             "cpu": cpu_model(), "threads": cores, "torch": torch.__version__,
+             "runs_s": [round(s, 2) for s in secs],
+             "sample": f"1 clip, {n_frames} of {T} frames timed; 1 warm-up + min of {runs} runs ({sec:.2f} s), same stages / inputs as "
+                       f"the GPU step; torch {torch.__version__} CPU fp32, {cores} threads on {cpu_model()}"}, outs)
+
+
+def parity_leg(last, cpu_out, wl, n_frames, ta, dtype):
+    """Clip 0 of the LAST timed GPU step vs the CPU oracle's outputs on the same inputs (cpu_baseline's last run).
+    err_of_scale = max|got - ref| / max|ref| per tensor; the gate is the north_star tolerance for exact fp32."""
+    import torch
+    res, out, x5, idx, score, bank = last
+    T, R = wl["T"], wl["R"]
+    n = max(1, min(n_frames, T))
+
+    def err(a, b):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    rf = torch.cat([res[f]["roi_features"] for f in range(n)])
+    with torch.no_grad():
+        if n == T:
+            x3_1b, gidx = out[0][:R], idx[:R]
+            gx5 = x5[:R] if x5 is not None else ta.pair(out[0][:R].contiguous(), bank)
+        else:       # fewer CPU frames than the step ran: the SEAM head again, on the same frame subset
+            ids = torch.arange(R, dtype=torch.int64).repeat(n)
+            o = ta(rf, torch.zeros(n * R, dtype=torch.int32), ids)
+            from seam_match_rcnn_amd import ops
+            x3_1b, gx5 = o[0], ta.pair(o[0], bank)
+            gidx, _ = ops.rank_topk(gx5, TOPK)
+    torch.cuda.synchronize()
+    errs = {"roi_features": err(rf, cpu_out["roi_features"]), "x3_1b": err(x3_1b, cpu_out["x3_1b"]),
+            "match_logits": err(gx5, cpu_out["x5"])}
+    gi, ci = gidx.cpu(), cpu_out["idx"]
+    rows_equal = int((gi == ci).all(1).sum())
+    overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, ci)) / float(ci.numel())
+    tol = PARITY_TOL if dtype == "f32" else (2e-3 if dtype == "bf16x3" else 5e-2)
+    worst = max(errs.values())
+    return {"checked": True, "against": "cpu_baseline outputs (oracle, same synthetic inputs), clip 0 of the last timed step",
+            "frames_compared": n, "max_err_of_scale": float(f"{worst:.3e}"),
+            "err_of_scale": {k: float(f"{v:.3e}") for k, v in errs.items()},
+            "topk_equal": rows_equal == gi.shape[0], "topk_rows_identical": f"{rows_equal}/{gi.shape[0]}",
+            "topk_set_overlap": round(overlap, 4), "tolerance": tol,
+            "ok": bool(worst <= tol and overlap >= (0.99 if dtype == "f32" else 0.9))}
 
 
 if __name__ == "__main__":

@@ -271,6 +271,28 @@ int seam_decode_boxes_f32(const float* deltas, const float* boxes_in, float* box
 int seam_nms_sorted_f32(const float* boxes, int* keep, int B, int N, float thr, uint64_t* mask_ws,
                         seam_stream_t stream);
 
+/* Same, stopping after the first max_keep survivors of each image (0 = no limit): greedy NMS decides a box from
+ * higher-scored boxes only, so the result equals the full scan truncated to max_keep survivors -- what the callers keep
+ * anyway ([TV] filter_proposals post_nms_top_n; postprocess_detections detections_per_img,
+ * models/video_matchrcnn.py:199-201). */
+int seam_nms_sorted_topn_f32(const float* boxes, int* keep, int B, int N, float thr, int max_keep,
+                             uint64_t* mask_ws, seam_stream_t stream);
+
+/* RPN filter_proposals, per pyramid level [TV RegionProposalNetwork._get_top_n_idx + BoxCoder.decode + clip + sigmoid]
+ * (SURVEY.md 8b `seam_rpn_decode_topk`): for each of n_img images the exact top-k of its n = H*W*A objectness logits
+ * (logit descending, anchor index ascending = the first k of a stable descending sort), and for the winners in that order
+ * the decoded (weights 1,1,1,1), clipped box, sigmoid(logit) and (optionally, index != NULL) the anchor index.
+ * obj / deltas are read in place from the head output: logit of anchor j = (pixel j / A, a = j % A) at
+ * obj[img*obj_img_stride + pixel*obj_pix_stride + a], its deltas at deltas[img*dlt_img_stride + pixel*dlt_pix_stride + 4a ..].
+ * anchors [n,4]; clip_hw [n_img,2] = (height, width) of each resized image; outputs are written at row
+ * img*out_img_stride + out_offset + rank (boxes [.,4], scores [.], index [.] int64).  k <= seam_rpn_topk_max() (1024), k <= n. */
+int seam_rpn_topk_max(void);
+int seam_rpn_topk_decode_f32(const float* obj, const float* deltas, const float* anchors,
+                             const float* clip_hw, float* boxes, float* scores, int64_t* index,
+                             int n_img, int n, int A, int k, int64_t obj_img_stride,
+                             int obj_pix_stride, int64_t dlt_img_stride, int dlt_pix_stride,
+                             int64_t out_img_stride, int out_offset, seam_stream_t stream);
+
 /* paste_masks_in_image [TV] (transform.postprocess, reached from model(images)): masks [K,1,28,28]
  * probabilities, boxes [K,4] (original-image px) -> out [K,1,H,W]. */
 int seam_paste_masks_f32(const float* masks, const float* boxes, float* out, int K, int H, int W,

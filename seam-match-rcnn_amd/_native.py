@@ -86,6 +86,9 @@ SIGNATURES = {
     "seam_pair_topk_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "seam_decode_boxes_f32": (_i, [_p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _p]),
     "seam_nms_sorted_f32": (_i, [_p, _p, _i, _i, _f, _p, _p]),
+    "seam_nms_sorted_topn_f32": (_i, [_p, _p, _i, _i, _f, _i, _p, _p]),
+    "seam_rpn_topk_max": (_i, []),
+    "seam_rpn_topk_decode_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, _i, _i64, _i, _i64, _i, _p]),
     "seam_paste_masks_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "seam_mask_select_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_conv_wgrad_workspace_floats": (_i64, [_i, _i, _i, _i, _i]),

@@ -30,6 +30,7 @@ from .. import ops
 
 RESNET50_LAYERS = ((3, 64, 1), (4, 128, 2), (6, 256, 2), (3, 512, 2))
 BBOX_XFORM_CLIP = math.log(1000.0 / 16)
+NMS_MAX_BOXES = 16384     # per-image capacity of seam_nms_sorted_f32 (csrc/seam_detect.hip)
 
 
 def _key(params, dtype=None) -> tuple:
@@ -324,13 +325,13 @@ class RPNHead(nn.Module):
     def forward(self, feats: Sequence[torch.Tensor]):
         """-> per level ([N,H,W,A] objectness, [N,H,W,4A] deltas), NHWC == torchvision's
         permute(0,2,3,1) order (h, w, anchor[, coord])."""
-        conv, heads = self.packed()
         a = self.num_anchors
-        out = []
-        for f in feats:
-            o = ops.conv2d(ops.conv2d(f, conv, relu=True), heads, out_f32=True)     # logits/deltas leave in fp32
-            out.append((o[..., :a], o[..., a:]))
-        return out
+        return [(o[..., :a], o[..., a:]) for o in self.fused(feats)]
+
+    def fused(self, feats: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """-> per level the fused head output [N,H,W,A+4A] fp32 (objectness logits | deltas of each pixel)."""
+        conv, heads = self.packed()
+        return [ops.conv2d(ops.conv2d(f, conv, relu=True), heads, out_f32=True) for f in feats]     # logits/deltas leave in fp32
 
 
 def _base_anchors(size: float, ratios=(0.5, 1.0, 2.0)) -> np.ndarray:
@@ -356,14 +357,15 @@ def grid_anchors(padded_hw, feat_hws, sizes=(32, 64, 128, 256, 512)) -> List[np.
     return out
 
 
-def batched_nms(boxes, scores, idxs, thr):
+def batched_nms(boxes, scores, idxs, thr, top_n: int = 0):
     """torchvision ``batched_nms`` (coordinate-offset form) for ONE image -> kept indices by descending
-    score.  The IoU bit-matrix and the greedy scan are HIP kernels; the sort is a device sort."""
+    score (the first ``top_n`` of them when top_n > 0).  The IoU bit-matrix and the greedy scan are HIP kernels;
+    the sort is a device sort."""
     if boxes.numel() == 0:
         return torch.zeros((0,), dtype=torch.int64, device=boxes.device)
     off = idxs.to(boxes) * (boxes.max() + 1.0)
     order = torch.argsort(scores, descending=True, stable=True)
-    keep = ops.nms_sorted((boxes + off[:, None])[order].contiguous(), thr)
+    keep = ops.nms_sorted((boxes + off[:, None])[order].contiguous(), thr, max_keep=int(top_n))
     return order[keep.bool()]
 
 
@@ -373,7 +375,7 @@ def batched_nms_images(boxes, scores, idxs, valid, thr, top_n):
     boxes [B,n,4], scores [B,n], idxs [B,n] (class / level id), valid [B,n] bool (entries removed by
     the score / small-box filters).  Per image: offset boxes by idx*(max_coord+1) (max over the
     image's valid boxes, as torchvision computes it on the filtered set), sort by score (stable,
-    descending), greedy NMS, keep the first ``top_n`` survivors.
+    descending), greedy NMS, keep the first ``top_n`` survivors (the scan kernel stops there).
     -> (order [B,n] int64: candidate index at each sorted position, sel [B,n] bool: sorted positions
     that survive).  No host synchronisation."""
     neg = torch.finfo(boxes.dtype).min
@@ -383,11 +385,11 @@ def batched_nms_images(boxes, scores, idxs, valid, thr, top_n):
     order = torch.argsort(sc, dim=1, descending=True, stable=True)
     sb = torch.gather(boxes + off[..., None], 1, order[..., None].expand(-1, -1, 4))
     sv = torch.gather(valid, 1, order)
-    # invalid entries become far-away degenerate boxes: they suppress nothing and are masked out below
+    # invalid entries become far-away degenerate boxes: they suppress nothing, sort behind every valid entry (so the scan's
+    # survivor count reaches them only after all valid survivors were counted) and are masked out below
     sb = torch.where(sv[..., None], sb, sb.new_full((), -1.0e8)).contiguous()
-    keep = ops.nms_sorted(sb, thr).bool() & sv
-    rank = torch.cumsum(keep.to(torch.int32), 1)
-    return order, keep & (rank <= top_n)
+    keep = ops.nms_sorted(sb, thr, max_keep=int(top_n)).bool() & sv
+    return order, keep
 
 
 class RegionProposalNetwork(nn.Module):
@@ -395,6 +397,12 @@ class RegionProposalNetwork(nn.Module):
                  pre_nms_top_n_train=2000, post_nms_top_n_train=2000):
         super().__init__()
         self.head = RPNHead()
+        if pre_nms_top_n_test < 1 or post_nms_top_n_test < 1:
+            raise ValueError("rpn_pre_nms_top_n_test / rpn_post_nms_top_n_test must be positive")
+        if 5 * pre_nms_top_n_test > NMS_MAX_BOXES:
+            # the batched NMS kernel scans at most NMS_MAX_BOXES candidates per image (5 pyramid levels x pre_nms_top_n)
+            raise ValueError(f"rpn_pre_nms_top_n_test = {pre_nms_top_n_test}: 5 levels x top-n exceeds the {NMS_MAX_BOXES} "
+                             f"candidates per image seam_nms_sorted_f32 handles (max {NMS_MAX_BOXES // 5})")
         self.pre_nms_top_n, self.post_nms_top_n = pre_nms_top_n_test, post_nms_top_n_test
         self.nms_thresh, self.min_size = nms_thresh, min_size
         self._anchor_cache = {}
@@ -406,19 +414,55 @@ class RegionProposalNetwork(nn.Module):
         return self._anchor_cache[key]
 
     def forward(self, feats: "OrderedDict[str, torch.Tensor]", image_sizes, padded_hw):
-        """RegionProposalNetwork.filter_proposals for the whole batch: per-level top-k (batched over
-        images), decode + clip, sigmoid, small-box filter, per-level NMS, first post_nms_top_n --
-        one host synchronisation (the variable-length split of the result) instead of ~20 per image."""
+        """RegionProposalNetwork.filter_proposals for the whole batch: per-level top-k + decode + clip + sigmoid in ONE
+        launch per level (``seam_rpn_topk_decode_f32``: a radix select over the logits in place, no device sort), small-box
+        filter, per-level NMS, first post_nms_top_n -- one host synchronisation (the variable-length split of the
+        result) instead of ~20 per image."""
         fl = list(feats.values())
-        head = self.head(fl)
         n = fl[0].shape[0]
         dev = fl[0].device
         anchors = self.anchors(padded_hw, [f.shape[1:3] for f in fl], dev)
+        a = self.head.num_anchors
+        ks = [min(self.pre_nms_top_n, f.shape[1] * f.shape[2] * a) for f in fl]
+        if max(ks) <= ops.rpn_topk_max():
+            heads = self.head.fused(fl)
+            ktot = sum(ks)
+            bx = torch.empty((n, ktot, 4), dtype=torch.float32, device=dev)
+            sc = torch.empty((n, ktot), dtype=torch.float32, device=dev)
+            off = 0
+            clip = self._clip_hw(image_sizes, dev)
+            for o, anc, k in zip(heads, anchors, ks):
+                ops.rpn_topk_decode(o, a, anc, clip, k, bx, sc, off)
+                off += k
+            lv = self._levels(tuple(ks), dev)[None].expand(n, -1)
+        else:
+            bx, sc, lv = self._topk_by_sort(self.head(fl), anchors, image_sizes, ks, n, dev)
+        valid = ((bx[..., 2] - bx[..., 0]) >= self.min_size) & ((bx[..., 3] - bx[..., 1]) >= self.min_size)
+        order, sel = batched_nms_images(bx, sc, lv, valid, self.nms_thresh, self.post_nms_top_n)
+        kept = torch.gather(bx, 1, order[..., None].expand(-1, -1, 4))
+        counts = sel.sum(1).tolist()                                                    # the one sync
+        return list(kept[sel].split(counts, 0))
+
+    def _clip_hw(self, image_sizes, dev):
+        key = ("clip", tuple(map(tuple, image_sizes)), str(dev))
+        if key not in self._anchor_cache:
+            if len(self._anchor_cache) > 64:
+                self._anchor_cache.clear()
+            self._anchor_cache[key] = torch.tensor([[float(h), float(w)] for h, w in image_sizes], dtype=torch.float32).to(dev)
+        return self._anchor_cache[key]
+
+    def _levels(self, ks, dev):
+        key = ("lv", ks, str(dev))
+        if key not in self._anchor_cache:
+            self._anchor_cache[key] = torch.cat([torch.full((k,), l, dtype=torch.int64) for l, k in enumerate(ks)]).to(dev)
+        return self._anchor_cache[key]
+
+    def _topk_by_sort(self, head, anchors, image_sizes, ks, n, dev):
+        """pre_nms_top_n beyond the select kernel's capacity (1024): per-level stable device sort + decode kernel."""
         bx, sc, lv = [], [], []
         same_size = all(tuple(s) == tuple(image_sizes[0]) for s in image_sizes)
-        for l, ((obj, dlt), anc) in enumerate(zip(head, anchors)):
+        for l, ((obj, dlt), anc, k) in enumerate(zip(head, anchors, ks)):
             o = obj.reshape(n, -1)
-            k = min(self.pre_nms_top_n, o.shape[1])
             top = torch.argsort(o, dim=1, descending=True, stable=True)[:, :k]          # ties -> lower index
             d = torch.gather(dlt.reshape(n, -1, 4), 1, top[..., None].expand(-1, -1, 4)).reshape(n * k, 4)
             a = anc[top.reshape(-1)]
@@ -430,12 +474,7 @@ class RegionProposalNetwork(nn.Module):
             bx.append(b.view(n, k, 4))
             sc.append(torch.sigmoid(torch.gather(o, 1, top)))
             lv.append(torch.full((n, k), l, dtype=torch.int64, device=dev))
-        bx, sc, lv = torch.cat(bx, 1), torch.cat(sc, 1), torch.cat(lv, 1)
-        valid = ((bx[..., 2] - bx[..., 0]) >= self.min_size) & ((bx[..., 3] - bx[..., 1]) >= self.min_size)
-        order, sel = batched_nms_images(bx, sc, lv, valid, self.nms_thresh, self.post_nms_top_n)
-        kept = torch.gather(bx, 1, order[..., None].expand(-1, -1, 4))
-        counts = sel.sum(1).tolist()                                                    # the one sync
-        return list(kept[sel].split(counts, 0))
+        return torch.cat(bx, 1), torch.cat(sc, 1), torch.cat(lv, 1)
 
 
 # ------------------------------------------------------------------------------ RoIAlign (a7)

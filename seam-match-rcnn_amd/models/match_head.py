@@ -143,7 +143,12 @@ class MatchPredictor(nn.Module):
         if _wants_tape(self, x):
             return self.trunk_taped(x)
         dt = getattr(self, "compute_dtype", torch.float32)
-        return self.trunk_nhwc(ops.nchw_to_nhwc(x.detach().to(torch.float32), torch.float16 if dt == torch.float16 else torch.float32))
+        x = x.detach()
+        if (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and dt != torch.float16 and x.shape[0] > 0
+                and x.permute(0, 2, 3, 1).is_contiguous()):
+            # channels_last input (what the extractor hands out as 'roi_features'): already the kernels' NHWC layout
+            return self.trunk_nhwc(x.permute(0, 2, 3, 1))
+        return self.trunk_nhwc(ops.nchw_to_nhwc(x.to(torch.float32), torch.float16 if dt == torch.float16 else torch.float32))
 
     def trunk_taped(self, x: torch.Tensor) -> torch.Tensor:
         """The trunk as ONE autograd node (fp32): forward kernels + BatchNorm1d batch statistics when the BN layer

@@ -36,6 +36,7 @@ class TemporalRoIHeads(nn.Module):
     library's NHWC FPN maps; everything else keeps the reference's meaning."""
 
     video = True                    # emit 'roi_features' (ref :314); NewRoIHeads does not
+    roi_features_contiguous = False  # True: 'roi_features' as a contiguous NCHW copy instead of a channels_last view
     fallback_score = 0.1            # ref :252 (1.0 in models/matchrcnn.py:377)
 
     def __init__(self, num_classes=91, n_frames=3, box_score_thresh=0.05, box_nms_thresh=0.5,
@@ -114,7 +115,7 @@ class TemporalRoIHeads(nn.Module):
             if s.numel() > 16384:
                 top = torch.argsort(s, descending=True, stable=True)[:16384]
                 b, s, labels = b[top], s[top], labels[top]
-            k = det.batched_nms(b, s, labels, self.nms_thresh)[:self.detections_per_img]
+            k = det.batched_nms(b, s, labels, self.nms_thresh, self.detections_per_img)
             out_b.append(b[k]); out_s.append(s[k]); out_l.append(labels[k])
         return out_b, out_s, out_l
 
@@ -157,7 +158,16 @@ class TemporalRoIHeads(nn.Module):
             # types = 0 for image 0's ROIs, 1 for all others (ref :299-307); the pairwise logits the
             # reference computes here are dropped by every caller (ref :309), only x3 is kept
             final_features = self.match_predictor.trunk_nhwc(roi_nhwc)
-            roi_nchw = ops.nhwc_to_nchw(roi_nhwc) if self.video else None
+            # 'roi_features' [K,256,14,14] (ref :314).  Exact-fp32 path: an NCHW-shaped VIEW of the NHWC tile RoIAlign wrote
+            # (torch's channels_last memory format: same shape, same values, no transpose pass) -- the aggregator, its only
+            # consumer (stuffs/engine.py:158, evaluate_movingfashion.py:42), reads that layout back without a copy.
+            # ``roi_features_contiguous = True`` restores a contiguous NCHW copy; the fp16 path always converts (fp32 output).
+            roi_nchw = None
+            if self.video:
+                if roi_nhwc.dtype == torch.float32 and not self.roi_features_contiguous:
+                    roi_nchw = roi_nhwc.permute(0, 3, 1, 2)
+                else:
+                    roi_nchw = ops.nhwc_to_nchw(roi_nhwc)
             off = 0
             for r, c in zip(result, counts):
                 r['match_features'] = final_features[off:off + c]

@@ -340,6 +340,10 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
             raise ValueError("conv2d: out_hw needs exact-fp32 weights, no residual and a size inside the full output")
         ho, wo = int(out_hw[0]), int(out_hw[1])
     ydt = F32 if (pc.dtype != F16 or out_f32) else F16
+    if out is not None:
+        if (not isinstance(out, torch.Tensor) or not out.is_cuda or out.device != x.device or tuple(out.shape) != (n, ho, wo, pc.K)
+                or out.dtype != ydt or not out.is_contiguous()):
+            raise ValueError(f"conv2d: out must be a contiguous {ydt} tensor of shape {(n, ho, wo, pc.K)} on {x.device}")
     y = out if out is not None else torch.empty((n, ho, wo, pc.K), dtype=ydt, device=x.device)
     if residual is not None:
         residual = _req(residual, F16 if pc.dtype == F16 else F32, "residual")
@@ -492,6 +496,11 @@ def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, 
     """normalise + resize + pad + CHW->NHWC for a list of fp32 images -> [N,hp,wp,4] fp32 / [N,hp,wp,8] fp16.
     ``s2d`` (fp32 [3,H,W] images only): the space-to-depth layout [N,hp/2,wp/2,12] of ``seam_preprocess_s2d_batch_f32``."""
     lib = _native.lib()
+    # device check FIRST, for every image and every branch below: a CPU tensor must raise SeamNativeError, never reach a
+    # kernel as a raw host pointer (the one-launch batch branches take data_ptr() of the views directly)
+    images = [_req(i, None, "image") for i in images]
+    if not images:
+        raise ValueError("preprocess: empty image list")
     if s2d:
         if dtype != F32 or hp % 2 or wp % 2 or any(i.dtype != F32 or i.dim() != 3 or i.shape[0] != 3 for i in images):
             raise ValueError("preprocess(s2d=True): fp32 [3,H,W] images and an even padded size")
@@ -597,6 +606,26 @@ def avgpool(x: torch.Tensor) -> torch.Tensor:
         fn = getattr(_native.lib(), "seam_avgpool_" + _sfx(x.dtype))
         _native.check(fn(_ptr(x), _ptr(y), k, l, c, _stream()), "seam_avgpool")
     return y
+
+
+def cat_rows(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """``torch.cat(parts, 0)`` without the copy when the parts are consecutive dim-0 slices of one allocation with equal
+    strides (the per-image ``roi_features`` / ``match_features`` views the model hands out are): returns the covering view."""
+    parts = list(parts)
+    if len(parts) == 1:
+        return parts[0]
+    p0 = parts[0]
+    if p0.dim() >= 1 and p0.shape[0] > 0:
+        st, es, ptr, rows, ok = p0.stride(), p0.element_size(), p0.data_ptr(), 0, True
+        for p in parts:
+            if (p.dtype != p0.dtype or p.device != p0.device or p.shape[1:] != p0.shape[1:] or p.shape[0] == 0 or p.stride() != st
+                    or p.untyped_storage().data_ptr() != p0.untyped_storage().data_ptr() or p.data_ptr() != ptr + rows * st[0] * es):
+                ok = False
+                break
+            rows += p.shape[0]
+        if ok:
+            return p0.as_strided((rows,) + tuple(p0.shape[1:]), st, p0.storage_offset())
+    return torch.cat(parts, 0)
 
 
 # ------------------------------------------------------------------------------ RoIAlign
@@ -764,8 +793,10 @@ def decode_boxes(deltas: torch.Tensor, boxes: torch.Tensor, weights, clip_hw=Non
     return out
 
 
-def nms_sorted(boxes: torch.Tensor, thr: float) -> torch.Tensor:
-    """boxes [N,4] or [B,N,4], already sorted by descending score (per image) -> keep mask int32 [N] / [B,N]."""
+def nms_sorted(boxes: torch.Tensor, thr: float, max_keep: int = 0) -> torch.Tensor:
+    """boxes [N,4] or [B,N,4], already sorted by descending score (per image) -> keep mask int32 [N] / [B,N].
+    max_keep > 0: only the first ``max_keep`` survivors of each image are marked (== the full result truncated; the scan stops
+    there)."""
     boxes = _req(boxes)
     single = boxes.dim() == 2
     b3 = boxes[None] if single else boxes
@@ -774,9 +805,43 @@ def nms_sorted(boxes: torch.Tensor, thr: float) -> torch.Tensor:
     if n and bsz:
         nb = (n + 63) // 64
         ws = torch.empty((bsz * n * nb,), dtype=torch.int64, device=boxes.device)
-        _native.check(_native.lib().seam_nms_sorted_f32(_ptr(b3), _ptr(keep), bsz, n, float(thr), _ptr(ws), _stream()),
-                      "seam_nms_sorted_f32")
+        _native.check(_native.lib().seam_nms_sorted_topn_f32(_ptr(b3), _ptr(keep), bsz, n, float(thr), int(max_keep), _ptr(ws),
+                                                             _stream()), "seam_nms_sorted_topn_f32")
     return keep[0] if single else keep
+
+
+def rpn_topk_max() -> int:
+    return int(_native.lib().seam_rpn_topk_max())
+
+
+def rpn_topk_decode(head: torch.Tensor, num_anchors: int, anchors: torch.Tensor, clip_hw: torch.Tensor, k: int,
+                    boxes: torch.Tensor, scores: torch.Tensor, offset: int, index: Optional[torch.Tensor] = None) -> None:
+    """One pyramid level of RPN ``filter_proposals`` [TV] in one launch (``seam_rpn_topk_decode_f32``).
+
+    head    [N,H,W,A+4A] fp32: the fused RPN head output (objectness logits | deltas per pixel), read in place
+    anchors [H*W*A,4]; clip_hw [N,2] (height, width of each resized image), both fp32 on the device
+    Writes, for every image, the top-``k`` anchors by logit (descending; ties lowest anchor index first) as decoded + clipped
+    boxes into ``boxes[:, offset:offset+k]`` ([N,Ktot,4]) and sigmoid scores into ``scores[:, offset:offset+k]`` ([N,Ktot]);
+    ``index`` (int64 [N,Ktot], optional) receives the anchor indices."""
+    lib = _native.lib()
+    head, anchors, clip_hw = _req(head, name="head"), _req(anchors, name="anchors"), _req(clip_hw, name="clip_hw")
+    n_img, h, w, c = head.shape
+    a = int(num_anchors)
+    if c != 5 * a or anchors.shape != (h * w * a, 4) or clip_hw.shape != (n_img, 2):
+        raise ValueError("rpn_topk_decode: head must be [N,H,W,5A], anchors [H*W*A,4], clip_hw [N,2]")
+    if (boxes.dtype != F32 or scores.dtype != F32 or not boxes.is_cuda or not boxes.is_contiguous() or not scores.is_contiguous()
+            or boxes.dim() != 3 or boxes.shape[0] != n_img or boxes.shape[2] != 4 or tuple(scores.shape) != tuple(boxes.shape[:2])
+            or offset < 0 or offset + k > boxes.shape[1]):
+        raise ValueError("rpn_topk_decode: boxes [N,Ktot,4] / scores [N,Ktot] fp32 contiguous with room for k rows at offset")
+    if index is not None and (index.dtype != torch.int64 or tuple(index.shape) != tuple(scores.shape) or not index.is_contiguous()):
+        raise ValueError("rpn_topk_decode: index must be int64 [N,Ktot] contiguous")
+    if k < 1 or k > h * w * a or k > int(lib.seam_rpn_topk_max()):
+        raise ValueError(f"rpn_topk_decode: k = {k} outside 1..min(n, {int(lib.seam_rpn_topk_max())})")
+    obj = C.c_void_p(head.data_ptr())
+    dlt = C.c_void_p(head.data_ptr() + 4 * a)
+    _native.check(lib.seam_rpn_topk_decode_f32(obj, dlt, _ptr(anchors), _ptr(clip_hw), _ptr(boxes), _ptr(scores), _ptr(index),
+                                               n_img, h * w * a, a, k, h * w * c, c, h * w * c, c, boxes.shape[1], offset,
+                                               _stream()), "seam_rpn_topk_decode_f32")
 
 
 def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, hw) -> torch.Tensor:

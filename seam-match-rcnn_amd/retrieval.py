@@ -41,12 +41,14 @@ def _world(group=None) -> int:
 
 
 class BankGather:
-    """Handle of an in-flight all-gather of the product bank (``wait()`` -> [G,256])."""
+    """Handle of an in-flight all-gather of the product bank (``wait()`` -> [G,256]).
+    ``events`` (when the gather was issued with ``timed=True`` on a HIP stream): (start, end) events recorded on the
+    stream the collective runs on, for ``elapsed_us()`` after a synchronisation."""
 
     def __init__(self, bank: torch.Tensor, g_total: int, work=None, stream=None, pad_rows: int = 0,
-                 sizes: Optional[List[int]] = None):
+                 sizes: Optional[List[int]] = None, events=None):
         self.bank, self.g_total, self.work, self.stream = bank, g_total, work, stream
-        self.pad_rows, self.sizes = pad_rows, sizes
+        self.pad_rows, self.sizes, self.events = pad_rows, sizes, events
 
     def wait(self) -> torch.Tensor:
         if self.work is not None:
@@ -59,13 +61,27 @@ class BankGather:
             return torch.cat(parts, 0)
         return self.bank
 
+    def elapsed_us(self) -> Optional[float]:
+        """Device time of the collective (call after the stream was synchronised); None when not timed."""
+        if self.events is None:
+            return None
+        return 1e3 * self.events[0].elapsed_time(self.events[1])
 
-def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stream=None) -> BankGather:
+
+def _gather_into_tensor(group=None) -> bool:
+    """Which collective form to issue -- decided ONCE from the process group's backend, so that every rank issues the
+    same call (a per-rank try/except could pair ``all_gather_into_tensor`` on one rank with ``all_gather`` on another
+    and deadlock): RCCL ("nccl") gathers into one tensor; other backends (gloo, CPU tests) use the list form."""
+    return str(dist.get_backend(group)).lower() == "nccl"
+
+
+def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stream=None, timed: bool = False) -> BankGather:
     """All-gather the per-rank descriptor shards ``local[g_r,256]`` (g_r from ``shard_range``)
     into the full bank, product order preserved.  Asynchronous: returns a ``BankGather``.
 
     side_stream: optional ``torch.cuda.Stream``; the collective is enqueued there (after the
-    producer of ``local`` on the current stream) so compute on the current stream overlaps it."""
+    producer of ``local`` on the current stream) so compute on the current stream overlaps it.
+    timed: bracket the collective with HIP events on the stream it runs on (``BankGather.elapsed_us``)."""
     world = _world(group)
     if world == 1:
         return BankGather(local, g_total)
@@ -80,21 +96,25 @@ def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stre
         pad[:src.shape[0]] = src
         src = pad
     bank = local.new_empty((world * m, local.shape[1]))
-    use_into = local.is_cuda or hasattr(dist, "all_gather_into_tensor")
+    into = _gather_into_tensor(group)
 
     def issue():
-        if use_into:
-            try:
-                return dist.all_gather_into_tensor(bank, src, group=group, async_op=True)
-            except (RuntimeError, NotImplementedError):
-                pass
+        if into:
+            return dist.all_gather_into_tensor(bank, src, group=group, async_op=True)
         return dist.all_gather(list(bank.view(world, m, -1).unbind(0)), src, group=group, async_op=True)
 
     if local.is_cuda and side_stream is not None:
         side_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side_stream):
+            ev = None
+            if timed:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             work = issue()
-        return BankGather(bank, g_total, work, side_stream, sizes=sizes if ragged else None)
+            if timed:
+                work.wait()             # stream-level wait (no host block): orders the end event behind the collective
+                ev[1].record()
+        return BankGather(bank, g_total, work, side_stream, sizes=sizes if ragged else None, events=ev)
     return BankGather(bank, g_total, issue(), None, sizes=sizes if ragged else None)
 
 

@@ -60,6 +60,41 @@ def test_product_path_fails_loudly_without_gpu(native):
         mp(torch.zeros(2, 256, 14, 14), torch.IntTensor([0, 1]))
 
 
+def test_cpu_images_raise_on_every_preprocess_branch():
+    """CPU images -- including constant-stride views of one CPU clip, which satisfy the one-launch batch branch --
+    must raise SeamNativeError before any pointer reaches a kernel (runs without a GPU: the check precedes every launch)."""
+    import seam_match_rcnn_amd._native as native
+    import seam_match_rcnn_amd.ops as ops
+    from seam_match_rcnn_amd.models.video_matchrcnn import videomatchrcnn_resnet50_fpn
+    clip = torch.zeros(3, 3, 64, 96)
+    for imgs, kw in ((list(clip.unbind(0)), dict(s2d=True)), (list(clip.unbind(0)), dict()), ([clip[0]], dict(s2d=True)),
+                     ([torch.zeros(64, 96, 3, dtype=torch.uint8)], dict()), (list(clip.unbind(0)), dict(dtype=torch.float16))):
+        with pytest.raises(native.SeamNativeError):
+            ops.preprocess(imgs, [(64, 96)] * len(imgs), 64, 96, **kw)
+    m = videomatchrcnn_resnet50_fpn(pretrained_backbone=False, num_classes=14).eval()
+    with torch.no_grad(), pytest.raises(native.SeamNativeError):
+        m(list(clip.unbind(0)))
+
+
+def test_ctor_rejects_rpn_top_n_beyond_the_nms_capacity():
+    from seam_match_rcnn_amd.models.detection import NMS_MAX_BOXES
+    from seam_match_rcnn_amd.models.video_matchrcnn import videomatchrcnn_resnet50_fpn
+    videomatchrcnn_resnet50_fpn(pretrained_backbone=False, num_classes=14, rpn_pre_nms_top_n_test=NMS_MAX_BOXES // 5)
+    with pytest.raises(ValueError):
+        videomatchrcnn_resnet50_fpn(pretrained_backbone=False, num_classes=14, rpn_pre_nms_top_n_test=NMS_MAX_BOXES // 5 + 1)
+
+
+def test_cat_rows_is_zero_copy_for_adjacent_views():
+    import seam_match_rcnn_amd.ops as ops
+    x = torch.arange(10 * 4 * 3 * 3, dtype=torch.float32).view(10, 3, 3, 4).permute(0, 3, 1, 2)    # channels_last [10,4,3,3]
+    parts = list(x.split([3, 2, 5]))
+    y = ops.cat_rows(parts)
+    assert y.data_ptr() == x.data_ptr() and y.stride() == x.stride() and torch.equal(y, x)
+    z = ops.cat_rows([parts[0], parts[2]])                                                        # not adjacent: a real cat
+    assert torch.equal(z, torch.cat([parts[0], parts[2]])) and z.data_ptr() != x.data_ptr()
+    assert torch.equal(ops.cat_rows([parts[1], parts[0]]), torch.cat([parts[1], parts[0]]))
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "seam-match-rcnn_amd")
     for d, _, fs in os.walk(pkg):

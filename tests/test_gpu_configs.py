@@ -88,7 +88,7 @@ def test_config4_shard_sized_match_50000_gallery(ta):
 def test_config5_shapes_fp32(ta):
     """config 5 shapes (30-frame clips, 64 ROI/frame, 1080p) on the fp32 path: sequences of T=30
     through NLB+pool, and one 1080p frame through resize + stem/layer1 against the oracle.
-    (The fp16-MFMA variant named by config 5 is not built yet; fp32 is the stricter result.)"""
+    (The fp16-MFMA path config 5 names is covered at full clip size by tests/test_gpu_config5.py.)"""
     from seam_match_rcnn_amd import ops
     from seam_match_rcnn_amd.models.detection import GeneralizedRCNNTransform, ResNet50Body
     m, p = ta

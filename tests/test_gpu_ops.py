@@ -459,3 +459,66 @@ def test_preprocess_uint8_frames(ops):
     ref1, sz1 = OD.transform(imgs, min_size=60, max_size=90)          # identity scale
     out1 = ops.preprocess([r.to(d) for r in raw], [tuple(s) for s in sz1], ref1.shape[-2], ref1.shape[-1])
     assert_close(out1[..., :3].permute(0, 3, 1, 2), ref1, atol_scale=1e-6)
+
+
+def test_nms_scan_with_max_keep_is_the_truncated_full_scan(ops):
+    """seam_nms_sorted_topn_f32: the first max_keep survivors of the full greedy scan, bit for bit, on sizes that cross the
+    64-box block / 64-word lane-slot boundaries (n up to 13 000 = the 13-class x 1000-proposal candidate set)."""
+    d = dev()
+    for seed, (b, n, span) in enumerate([(2, 700, 380.0), (3, 4507, 800.0), (2, 13000, 800.0), (1, 16384, 1200.0), (2, 65, 60.0)]):
+        ctr = torch.from_numpy(synth.uniform(synth.stream_id(900 + seed, "c"), (b, n, 2), 10, span))
+        wh = torch.from_numpy(synth.uniform(synth.stream_id(910 + seed, "wh"), (b, n, 2), 4, 0.35 * span))
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 2).to(d)
+        full = ops.nms_sorted(boxes, 0.5)
+        assert 0 < int(full[0].sum()) < n
+        for mk in (1, 7, 100, 1000, n + 5):
+            got = ops.nms_sorted(boxes, 0.5, max_keep=mk)
+            ref = full.bool() & (torch.cumsum(full, 1) <= mk)
+            assert torch.equal(got.bool(), ref), (n, mk)
+    # against the oracle's greedy NMS on one image
+    ctr = torch.from_numpy(synth.uniform(synth.stream_id(930, "c"), (3000, 2), 10, 600.0))
+    wh = torch.from_numpy(synth.uniform(synth.stream_id(931, "wh"), (3000, 2), 4, 200.0))
+    boxes1 = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    scores = torch.linspace(1.0, 0.0, 3000)
+    keep_ref = OD.nms(boxes1, scores, 0.5)
+    got = ops.nms_sorted(boxes1.to(d), 0.5, max_keep=50).cpu().bool()
+    assert torch.equal(torch.nonzero(got).squeeze(1), keep_ref[:50])
+
+
+def test_rpn_topk_decode_matches_sort_and_oracle(ops):
+    """seam_rpn_topk_decode_f32 (radix select + decode + clip + sigmoid, one launch per level) vs a stable descending sort
+    + the decode kernel (bit-identical boxes, same order) and vs the oracle's per-level top-k / decode / clip."""
+    d = dev()
+    from seam_match_rcnn_amd.models.detection import grid_anchors
+    n_img, a = 3, 3
+    sizes = [(200, 304), (192, 300), (180, 250)]
+    for lvl, (h, w, k) in enumerate([(50, 76, 1000), (25, 38, 1000), (13, 19, 741), (7, 10, 97), (40, 64, 1024)]):
+        head = rnd(950 + lvl, (n_img, h, w, 5 * a), "head")
+        head[..., :a] *= 3.0
+        if lvl == 1:        # heavy ties across the k-th position: quantised logits (lowest anchor index must win)
+            head[..., :a] = torch.round(head[..., :a] * 2) / 2
+        if lvl == 3:
+            head[1, ..., :a] = 0.25        # a constant row: the winners are anchors 0 .. k-1
+        anc = torch.from_numpy(grid_anchors((208, 320), [(h, w)], sizes=(32 * 2 ** min(lvl, 4),))[0])
+        clip = torch.tensor([[float(s[0]), float(s[1])] for s in sizes])
+        ktot = k + 11
+        bx = torch.full((n_img, ktot, 4), -7.0, device=d)
+        sc = torch.full((n_img, ktot), -7.0, device=d)
+        ix = torch.full((n_img, ktot), -7, dtype=torch.int64, device=d)
+        hd = head.to(d)
+        ops.rpn_topk_decode(hd, a, anc.to(d), clip.to(d), k, bx, sc, 5, ix)
+        torch.cuda.synchronize()
+        assert float(bx[:, :5].max()) == -7.0 and float(bx[:, 5 + k:].max()) == -7.0        # rows outside the level untouched
+        obj = head[..., :a].reshape(n_img, -1)
+        dlt = head[..., a:].reshape(n_img, -1, 4)
+        top = torch.argsort(obj, dim=1, descending=True, stable=True)[:, :k]
+        assert torch.equal(ix[:, 5:5 + k].cpu(), top), lvl
+        for i in range(n_img):
+            dd = dlt[i][top[i]]
+            ref_dev = ops.decode_boxes(dd.contiguous().to(d), anc[top[i]].contiguous().to(d), (1., 1., 1., 1.), sizes[i])
+            assert torch.equal(bx[i, 5:5 + k], ref_dev)
+            ref = OD.clip_boxes(OD.decode_boxes(dd, anc[top[i]]), sizes[i])
+            assert_close(bx[i, 5:5 + k], ref, atol_scale=1e-6)
+            assert_close(sc[i, 5:5 + k], torch.sigmoid(obj[i][top[i]]), rtol=1e-5, atol_scale=1e-6)
+    with pytest.raises(ValueError):
+        ops.rpn_topk_decode(hd, a, anc.to(d), clip.to(d), 1025, bx, sc, 0)

@@ -10,7 +10,7 @@ import seam_match_rcnn_amd.synth as synth
 dev = torch.device("cuda:0")
 model, sd = bench.build_model(dev)
 ta = model.roi_heads.temporal_aggregator
-T, R = bench.T, bench.R
+T, R = bench.WORKLOADS["c2"]["T"], bench.WORKLOADS["c2"]["R"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8          # clips per step
 frames = list(torch.cat([torch.from_numpy(synth.frames(c, T, 800, 800)) for c in range(B)]).to(dev).unbind(0))
 rois = [torch.from_numpy(synth.fixed_rois(R, 800, 800)).to(dev) for _ in range(T * B)]
