@@ -52,6 +52,28 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+#ifndef SEAM_W24_PK
+#define SEAM_W24_PK 1       // 1 (default): the in-loop input transform on packed fp32 VALU ops; 0: scalar-lane v_fma_f32 / v_add_f32
+#endif
+// The input transform's VALU work sits between fp32 MFMAs.  MI355X_MICROARCH.md lists packed fp32 VALU instructions as an
+// anti-lever beside (bf16) MFMAs; beside FP32 MFMAs that does not hold -- measured on the bench's twelve layer shapes
+// (gpurun_out/r02g_w24_scalar_valu.txt, one box): the scalar-lane form (72 v_fma/add/sub per chunk, SEAM_W24_PK=0) is 1-2 % SLOWER
+// than the packed form (36 v_pk_*): the fp32 MFMA and the fp32 VALU share the SIMD's FMA lanes, what counts is FMAs, not opcodes.
+__device__ __forceinline__ float s_fma(float c, float b, float a) {        // a + c * b, c wave-uniform (SGPR)
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(b), "v"(a));
+    return d;
+}
+__device__ __forceinline__ float s_add(float a, float b) {
+    float d;
+    asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float s_sub(float a, float b) {
+    float d;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ f32x4 fma4(f32x2 c, f32x4 b, f32x4 a) {        // a + c * b
     const f32x2 lo = pk_fma(c, __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(a, a, 0, 1));
     const f32x2 hi = pk_fma(c, __builtin_shufflevector(b, b, 2, 3), __builtin_shufflevector(a, a, 2, 3));
@@ -66,24 +88,37 @@ __device__ __forceinline__ f32x2 pk_fma_s(f32x2 cs, f32x2 b, f32x2 c) {
     return d;
 }
 __device__ __forceinline__ f32x4 fma4s(f32x2 cs, f32x4 b, f32x4 a) {      // a + cs * b
+#if SEAM_W24_PK
     const f32x2 lo = pk_fma_s(cs, __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(a, a, 0, 1));
     const f32x2 hi = pk_fma_s(cs, __builtin_shufflevector(b, b, 2, 3), __builtin_shufflevector(a, a, 2, 3));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+#else
+    const float c = cs[0];
+    return f32x4{s_fma(c, b[0], a[0]), s_fma(c, b[1], a[1]), s_fma(c, b[2], a[2]), s_fma(c, b[3], a[3])};
+#endif
 }
 __device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) {
+#if SEAM_W24_PK
     const f32x2 lo = pk_add(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
     const f32x2 hi = pk_add(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+#else
+    return f32x4{s_add(a[0], b[0]), s_add(a[1], b[1]), s_add(a[2], b[2]), s_add(a[3], b[3])};
+#endif
 }
 __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+#if SEAM_W24_PK
     const f32x2 lo = pk_sub(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
     const f32x2 hi = pk_sub(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+#else
+    return f32x4{s_sub(a[0], b[0]), s_sub(a[1], b[1]), s_sub(a[2], b[2]), s_sub(a[3], b[3])};
+#endif
 }
 
 #ifndef SEAM_W24_ABL
 #define SEAM_W24_ABL 0      // kernel experiments (tools/experiments/wino24_abl.sh; operands keep the REAL data of chunks 0/1):
-                            // 1 no in-loop patch loads / LDS stores, 2 no in-loop weight loads, 4 no barrier, 8 no in-loop transforms
+                            // 1 no in-loop patch loads / LDS stores, 2 no in-loop weight loads, 4 no barrier, 8 no in-loop transforms, 16 no epilogue
 #endif
 
 struct Wino24Args {
@@ -108,11 +143,16 @@ struct Wino24Args {
     int tiles_y;
     int PH;
     int G;
+    int nt;               // n-tiles per block (kernel template NT)
     int tiles_n;          // K / (32 * NT)
     int nchunks;          // C / 8
     // ceil(2^32 / d) of the divisors the block prologue needs (fdiv below): an integer division costs ~20 VALU instructions,
     // and VALU instructions of either resident block delay the matrix pipe
     unsigned m_tiles_n, m_per_img, m_tys, m_pitch, m_bx[3], m_TX[3], m_PW[3];
+    // n-tile split over XCD groups (see the kernel's tile decode): nsplit groups, tns = tiles_n / nsplit n-tiles per group, the
+    // patches (tm) cut into 8 / nsplit partitions of part_q (+1 for the first part_r) each
+    int nsplit, tns, part_q, part_r;
+    unsigned m_tns;
 };
 
 // a / d for 0 <= a, a * d < 2^32, with m = ceil(2^32 / d) (d >= 2) -- one v_mul_hi_u32 / s_mul_hi_u32
@@ -128,37 +168,19 @@ constexpr int RAWB = (2 * ENTMAX + 1) * 16;        // bytes per raw buffer (+1 d
 // kernel: a SIMD does not overlap its MFMAs with anything else it issues -- one resident block instead of two costs only 10 %,
 // MFMAs-only runs at the same speed with one or two blocks, and the K loop's time is the sum of its MFMA cycles and ~16 cycles per
 // other vector instruction -- so what counts is MFMAs per transform / LDS / load instruction, not occupancy.
-template <int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Wino24Args p) {
-    // two raw patch buffers; the epilogue's exchange array ex[xi][b][tile][n] (64 KiB, all four output columns of a tile in one
-    // pass) reuses the same memory after the K loop
-    constexpr int EXB = 4 * 4 * 32 * 32 * 4;
-    static_assert(2 * RAWB <= EXB, "the raw buffers live inside the exchange array's 64 KiB");
-    __shared__ __attribute__((aligned(16))) char smem[EXB];
+// HSC: the LDS phase stride HS = (TX + 1) | 1 as a compile-time constant (0 = take it from TX at run time).  With a constant HS every
+// ds_read_b128 of the input transform is one base register + an immediate offset; with a run-time HS the compiler keeps 8-12 loop-
+// invariant address registers per buffer alive through the K loop (and, in the NT = 2 form, spills them to AccVGPRs and reads them
+// back every chunk).  The kernel dispatches on the block's region: HS = 9 (TX 7..8: the main region of every large map), 5 (TX 3..4),
+// 3 (TX <= 2: the right-hand strips), anything else through the run-time form.
+template <int NT, int HSC>
+__device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const int reg, const int rb, const int tm, const int tn,
+                                          const int tm_img) {
     char (*raw)[RAWB] = reinterpret_cast<char (*)[RAWB]>(smem);
     float* const ex = reinterpret_cast<float*>(smem);
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int xi = tid >> 6;
-
-    // ---- XCD-aware tile id (bijective) ----------------------------------------------------------------------------
-    const int nblk = gridDim.x;
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int q8 = nblk >> 3, rem8 = nblk & 7;
-    const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
-    const int tm = fdiv(tile, p.tiles_n, p.m_tiles_n);
-    const int tn = tile - tm * p.tiles_n;
-    const int per_img = p.per_img;
-    const int tm_img = fdiv(tm, per_img, p.m_per_img);
-    int rb = tm - tm_img * per_img;
-    int reg = 0;
-    if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
-        rb -= p.bx[0] * p.by[0];
-        reg = 1;
-        if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
-    }
     const int TX = p.TX[reg], TY = p.TY[reg];
     const int byi = fdiv(rb, p.bx[reg], p.m_bx[reg]);
     const int bxi = rb - byi * p.bx[reg];
@@ -173,7 +195,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
 
     const int PW = 4 * TX + 2, PH = p.stack ? p.PH : 2 * TY + 2;
     const int NPIX = PW * PH;
-    const int HS = (TX + 1) | 1;                           // 16-byte entries per (patch row, x mod 4); odd: the four x phases of
+    const int HS = HSC ? HSC : ((TX + 1) | 1);             // 16-byte entries per (patch row, x mod 4); odd: the four x phases of
                                                            // consecutive pixels land in four different 16-byte bank groups (stores)
     // A pair of patch rows (= one tile row step) takes PR entries, PR = 8 * HS rounded up to TX (mod 8): tile (r, tx) then
     // sits at r * PR + tx = lane (mod 8) -- the eight lanes of a ds_read_b128 phase always hit eight different 16-byte
@@ -225,14 +247,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
         goff[i] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + half * 4) * 4) : kOob;
         loff[i] = ok ? (half * NENT + (v >> 1) * PR + ((v & 1) * 4 + (px & 3)) * HS + (px >> 2)) * 16 : 2 * ENTMAX * 16;
     }
-    const int last_chunk = p.nchunks - 1;
     constexpr int NRS = NT == 1 ? 2 : 1;     // register sets of the raw patch: prefetch distance 2 chunks / 1 (twice as long) chunk
     f32x4 rset[NRS][NI];
     auto load_raw = [&](f32x4 (&rs)[NI], int chunk) {
-        const int c = chunk < last_chunk ? chunk : last_chunk;     // past the end: re-read the last chunk (never used)
+        // chunks past the end (the prefetch runs 2-4 ahead) are not clamped: they read the next pixel's channels or fall outside
+        // the descriptor (zero fill) and are never used -- one scalar shift per chunk instead of a compare/select per load group
+        const int so = chunk * 32;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
-            rs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[i], c * 32, 0));
+            rs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[i], so, 0));
     };
     auto store_raw = [&](const f32x4 (&rs)[NI], int buf) {
 #pragma unroll
@@ -243,14 +266,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
     const int ntile_bytes = p.nchunks * 24576;
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.u + (size_t)tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
-    const int uoff[1] = {(xi * 6 * 64 + lane) * 16};
+    // lane offsets of positions nu = 0..3 and 4..5: the per-position 1 KiB steps then fit the instruction's 12-bit immediate, and the
+    // scalar offset is one value per chunk (and n-tile).  Chunks past the end are not clamped: they read the next n-tile's first
+    // chunk or fall outside the descriptor (zero fill), and are never used.
+    const int uoff[2] = {(xi * 6 * 64 + lane) * 16, (xi * 6 * 64 + lane) * 16 + 4096};
     constexpr int NBS = NT == 1 ? 2 : 1;     // weight register sets: NT = 2 keeps ONE that rolls (arch VGPRs are the limit there)
     f32x4 bfs[NBS][NT][6];
     auto load_b = [&](f32x4 (&bf)[NT][6], int nu, int chunk) {       // position nu of every n-tile
-        const int c = chunk < last_chunk ? chunk : last_chunk;
+        const int so = chunk * 24576;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            bf[nt][nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff[0], c * 24576 + nu * 1024 + nt * ntile_bytes, 0));   // one lane offset; the rest is scalar
+            bf[nt][nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff[nu >> 2] + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
     };
 
     // ---- input transform --------------------------------------------------------------------------------------------
@@ -421,6 +447,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
     // ---- epilogue: output transform + scale/shift (+ residual, ReLU) ------------------------------------------------
     //   columns (A4t over nu): Y0 = m0+m1+m2+m3+m4, Y1 = (m1-m2) + 2(m3-m4), Y2 = (m1+m2) + 4(m3+m4), Y3 = (m1-m2) + 8(m3-m4) + m5
     //   rows (A2t over xi, across the waves): y0 = q0+q1+q2, y1 = q1-q2-q3
+    if (SEAM_W24_ABL & 16) {            // experiment: no epilogue (one conditional store keeps the accumulators alive)
+        float sum = 0.f;
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[nu][nt][r];
+        if (sum == 123456.789f) p.y[tid] = sum;
+        return;
+    }
     const size_t out_img = (size_t)p.Ho * p.Wo * p.K * 4;
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((char*)p.y + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
@@ -445,9 +482,20 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
             const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                const f32x2 m0 = {acc[0][nt][2 * h], acc[0][nt][2 * h + 1]}, m1 = {acc[1][nt][2 * h], acc[1][nt][2 * h + 1]};
-                const f32x2 m2 = {acc[2][nt][2 * h], acc[2][nt][2 * h + 1]}, m3 = {acc[3][nt][2 * h], acc[3][nt][2 * h + 1]};
-                const f32x2 m4 = {acc[4][nt][2 * h], acc[4][nt][2 * h + 1]}, m5 = {acc[5][nt][2 * h], acc[5][nt][2 * h + 1]};
+                // NT = 2: the 192 accumulators live in AccVGPRs; read the 12 values of this step explicitly, one step at a time --
+                // left to itself the compiler copies ALL of them into arch VGPRs at the loop exit and pays for that register peak
+                // by spilling the K loop's address registers
+                auto rd = [&](int nu) -> f32x2 {
+                    if constexpr (NT == 2) {
+                        float x0, x1;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(acc[nu][nt][2 * h]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(acc[nu][nt][2 * h + 1]));
+                        return f32x2{x0, x1};
+                    } else {
+                        return f32x2{acc[nu][nt][2 * h], acc[nu][nt][2 * h + 1]};
+                    }
+                };
+                const f32x2 m0 = rd(0), m1 = rd(1), m2 = rd(2), m3 = rd(3), m4 = rd(4), m5 = rd(5);
                 const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
                 const f32x2 y0 = pk_add(pk_add(m0, s12), s34);
                 const f32x2 y1 = pk_fma_s(c2, d34, d12);
@@ -494,6 +542,54 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
             }
         }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Wino24Args p) {
+    // two raw patch buffers; the epilogue's exchange array ex[xi][b][tile][n] (64 KiB, all four output columns of a tile in one
+    // pass) reuses the same memory after the K loop
+    constexpr int EXB = 4 * 4 * 32 * 32 * 4;
+    static_assert(2 * RAWB <= EXB, "the raw buffers live inside the exchange array's 64 KiB");
+    __shared__ __attribute__((aligned(16))) char smem[EXB];
+
+    // ---- XCD-aware tile id (bijective) ----------------------------------------------------------------------------
+    const int nblk = gridDim.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    int tm, tn;
+    if (p.nsplit > 1) {
+        // The n-tiles are split over `nsplit` groups of XCDs (workgroup b runs on XCD b & 7): XCD x streams only the n-tile subset
+        // g = x % nsplit -- its share of the transformed weights (24*K*C*4 / nsplit bytes) stays in the XCD's 4 MiB L2 instead of
+        // being re-streamed from the Infinity Cache by every generation of resident blocks, so the latency-critical weight loads
+        // hit -- and the 8 / nsplit XCDs of a group share the patch range of partition pi = x / nsplit (every patch is then read
+        // by nsplit XCDs: patch loads run 2+ chunks ahead and tolerate the miss).
+        const int g = xcd % p.nsplit, pi = xcd / p.nsplit;
+        const int j = b >> 3;
+        const int tml = fdiv(j, p.tns, p.m_tns);
+        tn = g * p.tns + (j - tml * p.tns);
+        const int size = p.part_q + (pi < p.part_r ? 1 : 0);
+        if (tml >= size) return;                           // padding blocks of the shorter partitions
+        tm = pi * p.part_q + min(pi, p.part_r) + tml;
+    } else {
+        const int q8 = nblk >> 3, rem8 = nblk & 7;
+        const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
+        tm = fdiv(tile, p.tiles_n, p.m_tiles_n);
+        tn = tile - tm * p.tiles_n;
+    }
+    const int per_img = p.per_img;
+    const int tm_img = fdiv(tm, per_img, p.m_per_img);
+    int rb = tm - tm_img * per_img;
+    int reg = 0;
+    if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
+        rb -= p.bx[0] * p.by[0];
+        reg = 1;
+        if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
+    }
+    const int hs = (p.TX[reg] + 1) | 1;                    // block-uniform
+    if (hs == 9) w24_block<NT, 9>(p, smem, reg, rb, tm, tn, tm_img);
+    else if (hs == 3) w24_block<NT, 3>(p, smem, reg, rb, tm, tn, tm_img);
+    else if (hs == 5) w24_block<NT, 5>(p, smem, reg, rb, tm, tn, tm_img);
+    else w24_block<NT, 0>(p, smem, reg, rb, tm, tn, tm_img);
 }
 
 // OIHW fp32 [K, Cin, 3, 3] -> U = G2 g G4t in MFMA fragment order: [K/32][Cstore/8][24][64][4]
@@ -650,9 +746,20 @@ inline bool wino_ok(int C, int K, int R, int S, int stride) { return R == 3 && S
 // 3-13 % elsewhere -- the register allocator parks the loop-invariant LDS / load addresses and 8 transform registers in spare
 // AccVGPRs and re-reads them (~60 v_accvgpr_read per 96 MFMAs) although ~90 arch VGPRs stay unused in the loop, and an asm MFMA
 // with pinned register classes did not change that.  SEAM_W24_NT=2 enables it for experiments.
-inline int wino24_nt(int K) {
-    static const int force = getenv("SEAM_W24_NT") ? atoi(getenv("SEAM_W24_NT")) : 1;
-    return (force == 2 && K % 64 == 0) ? 2 : 1;
+inline int wino24_nt(int K, int C, long blocks_nt1) {
+    // NT = 2 pays where the K loop is long enough to amortise a block that is alone on its CU (C >= 256) and the launch still fills
+    // the chip several times over with half as many blocks (measured per layer shape with tools/w24_ab.py; both forms compute
+    // bit-identical results, so the choice may depend on the batch).  SEAM_W24_NT=1|2 forces a form.
+    static const int force = getenv("SEAM_W24_NT") ? atoi(getenv("SEAM_W24_NT")) : 0;
+    if (K % 64) return 1;
+    if (force == 1 || force == 2) return force;
+    return (C >= 256 && blocks_nt1 / 2 >= 1024) ? 2 : 1;
+}
+
+// XCD groups the n-tiles are split over (1 = every XCD walks all n-tiles of its patches).  Default off until measured per shape.
+inline int wino24_nsplit(int C, int K, long patch_blocks) {
+    (void)C; (void)K; (void)patch_blocks;
+    return 1;
 }
 
 int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long& blocks) {
@@ -663,7 +770,8 @@ int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long&
     if ((size_t)H * W * C * 4 >= kOob || (size_t)a.Ho * a.Wo * K * 4 >= kOob) return (int)hipErrorInvalidValue;
     const int tiles_x = (a.Wo + 3) / 4, tiles_y = (a.Ho + 1) / 2;
     const Layout pp = choose_layout(N, tiles_x, tiles_y, (size_t)H * W * C * 4, (size_t)a.Ho * a.Wo * K * 4);
-    a.tiles_n = K / (32 * wino24_nt(K));
+    a.nt = wino24_nt(K, C, pp.blocks * (K / 32));
+    a.tiles_n = K / (32 * a.nt);
     a.nchunks = C / 8;
     a.nreg = pp.nreg; a.G = pp.G; a.per_img = (int)pp.per_img;
     a.stack = pp.stack; a.PH = pp.PH; a.tiles_y = tiles_y;
@@ -673,8 +781,19 @@ int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long&
         a.TX[r] = pp.TX[q]; a.TY[r] = pp.TY[q]; a.bx[r] = pp.bx[q]; a.by[r] = pp.by[q];
     }
     blocks = pp.blocks * a.tiles_n;
+    {
+        static const int want = getenv("SEAM_W24_NSPLIT") ? atoi(getenv("SEAM_W24_NSPLIT")) : 0;
+        int ns = want > 0 ? want : wino24_nsplit(C, K, pp.blocks);
+        while (ns > 1 && (a.tiles_n % ns || 8 % ns)) ns >>= 1;
+        a.nsplit = ns < 1 ? 1 : ns;
+        a.tns = a.tiles_n / a.nsplit;
+        const int parts = 8 / a.nsplit;
+        a.part_q = (int)(pp.blocks / parts); a.part_r = (int)(pp.blocks % parts);
+        if (a.nsplit > 1) blocks = 8L * (a.part_q + (a.part_r ? 1 : 0)) * a.tns;
+    }
     if (blocks >= (1L << 24)) return (int)hipErrorInvalidValue;     // also keeps every fdiv operand inside a * d < 2^32
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+    a.m_tns = magic(a.tns);
     a.m_tiles_n = magic(a.tiles_n); a.m_per_img = magic(a.per_img); a.m_tys = magic(tiles_y); a.m_pitch = magic(2 * tiles_y + 2);
     for (int r = 0; r < 3; ++r) { a.m_bx[r] = magic(a.bx[r]); a.m_TX[r] = magic(a.TX[r]); a.m_PW[r] = magic(4 * a.TX[r] + 2); }
     return 0;
@@ -701,7 +820,8 @@ long long seam_wino24_issue_slots(int N, int H, int W, int C, int K, int pad) {
     Wino24Args a;
     long blocks;
     if (wino24_plan(a, N, H, W, C, K, pad, blocks)) return 0;
-    return (long long)blocks * wino24_nt(K) * 32 * 24;
+    const long work = a.nsplit > 1 ? ((long)(8 / a.nsplit) * a.part_q + a.part_r) * a.tiles_n : blocks;     // without the padding blocks
+    return (long long)work * a.nt * 32 * 24;
 }
 
 int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* scale, const float* shift, const float* residual,
@@ -713,7 +833,7 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
     a.x = x; a.u = u_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.relu = relu;
     static const int dyn = getenv("SEAM_W24_DYNLDS") ? atoi(getenv("SEAM_W24_DYNLDS")) : 0;     // dev knob: occupancy experiments
-    if (wino24_nt(K) == 2) hipLaunchKernelGGL(conv3x3_wino24<2>, dim3((unsigned)blocks), dim3(256), dyn, (hipStream_t)stream, a);
+    if (a.nt == 2) hipLaunchKernelGGL(conv3x3_wino24<2>, dim3((unsigned)blocks), dim3(256), dyn, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv3x3_wino24<1>, dim3((unsigned)blocks), dim3(256), dyn, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

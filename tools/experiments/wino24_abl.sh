@@ -1,8 +1,8 @@
 #!/bin/bash
 # Ablation builds of the F(2x4,3x3) Winograd kernel (SEAM_W24_ABL bits: 1 no patch loads / LDS stores, 2 no weight loads,
-# 4 no barrier, 8 no transforms; operands keep real data).  `build [bits...]` in the dev container, `run [shapes...]` on the GPU box.
+# 4 no barrier, 8 no transforms, 16 no epilogue; operands keep real data).  `build [bits...]` in the dev container, `run [shapes...]` on the GPU box.
 cd "$(dirname "$0")/../.." || exit 1
-C=seam-match-rcnn_amd/csrc; L=seam-match-rcnn_amd/lib/abl24
+C=seam-match-rcnn_amd/csrc; L=tools/experiments/_lib     # travels with gpurun (*.so is git-ignored); delete after the experiment
 if [ "$1" = build ]; then
   shift
   mkdir -p $L
@@ -12,6 +12,6 @@ if [ "$1" = build ]; then
   done
 else
   shift
-  python tools/wino_bench.py "$@" | tail -n +2
-  for f in $L/libseam_abl*.so; do echo "== $f"; SEAM_LIB_PATH=$PWD/$f python tools/wino_bench.py "$@" 2>/dev/null | tail -n +2; done
+  python tools/w24_ab.py "$@" 2>/dev/null | tail -n +3
+  for f in $(ls $L/libseam_abl*.so | sort -V); do echo "== $f"; SEAM_LIB_PATH=$PWD/$f python tools/w24_ab.py "$@" 2>/dev/null | tail -n +3; done
 fi

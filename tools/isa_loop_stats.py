@@ -60,28 +60,28 @@ def main():
             m = re.match(r"^(\.LBB\S+):", l)
             if m:
                 labels[m.group(1)] = i
-        best = None
+        loops = []
         for i, l in enumerate(body):
             m = re.match(r"^\s+s_cbranch_\S+\s+(\.LBB\S+)", l) or re.match(r"^\s+s_branch\s+(\.LBB\S+)", l)
             if m and m.group(1) in labels and labels[m.group(1)] < i:
-                seg = body[labels[m.group(1)]:i + 1]
-                n = sum("v_mfma" in s for s in seg)
-                if best is None or n > best[0]:
-                    best = (n, seg)
-        if best is None:
-            continue
-        cnt = collections.Counter()
-        for s in best[1]:
-            s = s.strip()
-            if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
-                continue
-            cnt[classify(s.split()[0])] += 1
-        regs = [l.strip() for l in body if re.search(r"\.(vgpr_count|sgpr_count|agpr_count)|NumVgprs|NumAgprs|ScratchSize|Occupancy", l)]
+                loops.append((labels[m.group(1)], i))
+        # innermost loops that hold MFMAs: no other loop strictly inside
+        inner = [(a, b) for a, b in loops if not any((c > a or d < b) and c >= a and d <= b for c, d in loops if (c, d) != (a, b))]
         print(name[:110])
-        tot = sum(cnt.values())
-        print("  loop instrs:", tot, dict(cnt.most_common()))
-        if cnt["mfma"]:
-            print("  non-MFMA per MFMA: %.2f" % ((tot - cnt["mfma"]) / cnt["mfma"]))
+        for a, b in inner:
+            seg = body[a:b + 1]
+            if not any("v_mfma" in x for x in seg):
+                continue
+            cnt = collections.Counter()
+            for x in seg:
+                x = x.strip()
+                if not x or x.startswith(";") or x.startswith(".") or x.endswith(":"):
+                    continue
+                cnt[classify(x.split()[0])] += 1
+            tot = sum(cnt.values())
+            print(f"  loop @{a}-{b}: {tot} instrs", dict(cnt.most_common()),
+                  "| non-MFMA per MFMA: %.2f" % ((tot - cnt["mfma"]) / max(1, cnt["mfma"])))
+        regs = [l.strip() for l in body if re.search(r"\.(vgpr_count|sgpr_count|agpr_count)|NumVgprs|NumAgprs|ScratchSize|Occupancy", l)]
         for r in regs[:8]:
             print("  ", r)
 
