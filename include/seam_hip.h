@@ -59,6 +59,7 @@ int seam_conv_tile(int M, int K);                  /* host helper: BM*1000+BN of
                                                       picks for an [M x K] output (128 or 64 each) */
 int seam_conv_tile_prec(int prec, int M, int K);   /* same for prec 0 = fp32, 1 = fp16, 2 = split-bf16 (these two also
                                                       have a 256x128 tile run by 8 waves) */
+int seam_conv_tile_taps(int prec, int M, int K, int taps);   /* ... for a layer with R*S = taps (the fp16 choice depends on it) */
 
 /* Pack an OIHW weight [K,Cin,R,S] (PyTorch layout) into the kernel's slab layout
  * (rows_padded*kred floats; reduction chunks ordered (r, c-chunk, s); channels >= Cin zero-filled).

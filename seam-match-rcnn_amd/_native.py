@@ -30,6 +30,7 @@ SIGNATURES = {
     "seam_conv_rows_padded": (_i, [_i]),
     "seam_conv_tile": (_i, [_i, _i]),
     "seam_conv_tile_prec": (_i, [_i, _i, _i]),
+    "seam_conv_tile_taps": (_i, [_i, _i, _i, _i]),
     "seam_pack_conv_weight_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_linear_narrow_supported": (_i, [_i, _i]),

@@ -87,6 +87,10 @@ __device__ __forceinline__ void split_row(const ConvArgs& p, int HoWo, int rl, i
     }
 }
 
+// Measured and not kept (round 2, gpurun_out/r02j_f16_wave128.txt): the fp16 256 x 128 tile as 4 waves of 128 x 64 (0.75 LDS fragment
+// reads per MFMA instead of 1, 128 accumulators, one block of 4 waves per CU) runs 763 TFLOP/s on the 80 x 200^2 x 256 -> 256 layer
+// against 859 for the same tile as 8 waves of 64 x 64: the 16-bit kernels are bound by load latency, not by LDS bandwidth, and four
+// waves per CU hide less of it.
 template <typename T, int BM, int BN, int NW, bool DUAL = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const ConvArgs p) {
     constexpr bool F16 = sizeof(T) == 2;
@@ -876,13 +880,16 @@ int pack_weight(const float* w, void* w_packed, int K, int Cin, int R, int S, in
 // input patch of a tile in LDS once per channel chunk and running all taps from it (next round).
 enum Prec { P_F32 = 0, P_F16 = 1, P_BX3 = 2 };
 
-inline int tile_weight(int prec, int bm, int bn) {
+inline int tile_weight(int prec, int bm, int bn, int taps) {
     const int area = bm * bn;
     if (prec == P_F32) return area == 256 * 128 ? 100 : area == 128 * 128 ? 100 : area == 64 * 64 ? 125 : 110;
-    return area == 256 * 128 ? (prec == P_BX3 ? 95 : 105) : area == 128 * 128 ? 100 : area == 64 * 64 ? 200 : 150;
+    // fp16: the 256 x 128 / 8-wave tile wins on the 3x3 layers (859 vs 752 TFLOP/s at 80 x 200^2 x 256 -> 256, +3-5 % at 100^2 and on
+    // the 14 x 14 ROI maps) and loses 3-5 % on the 1x1 layers (gpurun_out/r02j_f16_wave128.txt)
+    if (prec == P_F16 && area == 256 * 128) return taps >= 9 ? 92 : 105;
+    return area == 256 * 128 ? 95 : area == 128 * 128 ? 100 : area == 64 * 64 ? 200 : 150;
 }
 
-inline void choose_tile(int prec, int M, int K, int& best_bm, int& best_bn) {
+inline void choose_tile(int prec, int M, int K, int& best_bm, int& best_bn, int taps = 1) {
     const int rows = ((K + 63) / 64) * 64;
     const int slab = rows % 128 == 0 ? 128 : 64;
     static const char* force = getenv("SEAM_CONV_TILE");           // kernel experiments: "256x128", "128x128", ...
@@ -901,7 +908,7 @@ inline void choose_tile(int prec, int M, int K, int& best_bm, int& best_bn) {
         for (int bn = slab; bn >= 64; bn -= 64) {
             if (bm == 256 && (bn != 128 || prec == P_F32)) continue;       // 8-wave tile: 256x128 only; no gain for exact fp32
             const long nb = (long)((M + bm - 1) / bm) * (rows / bn);
-            const long cost = ((nb + 255) / 256) * bm * bn * tile_weight(prec, bm, bn);
+            const long cost = ((nb + 255) / 256) * bm * bn * tile_weight(prec, bm, bn, taps);
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_bm = bm; best_bn = bn; }
         }
 }
@@ -953,7 +960,7 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     const int rows = ((K + 63) / 64) * 64;
     a.slab_bn = rows % 128 == 0 ? 128 : 64;
     int best_bm, best_bn;
-    choose_tile(sizeof(T) == 2 ? P_F16 : P_F32, a.M, K, best_bm, best_bn);
+    choose_tile(sizeof(T) == 2 ? P_F16 : P_F32, a.M, K, best_bm, best_bn, R * S);
     a.tiles_m = (a.M + best_bm - 1) / best_bm;
     a.tiles_n = rows / best_bn;
     // persistent blocks: one per resident slot (256 CUs x 2 blocks of 4 waves, or x 1 block of 8 waves); a multiple of 8 so
@@ -1027,9 +1034,14 @@ int seam_conv_tile(int M, int K) {      // BM * 1000 + BN the fp32 launcher will
     choose_tile(P_F32, M, K, bm, bn);
     return bm * 1000 + bn;
 }
-int seam_conv_tile_prec(int prec, int M, int K) {      // same for prec 0 fp32 | 1 fp16 | 2 split-bf16
+int seam_conv_tile_prec(int prec, int M, int K) {      // same for prec 0 fp32 | 1 fp16 | 2 split-bf16 (a 1x1 layer)
     int bm, bn;
     choose_tile(prec, M, K, bm, bn);
+    return bm * 1000 + bn;
+}
+int seam_conv_tile_taps(int prec, int M, int K, int taps) {      // ... of a layer with R*S = taps (the fp16 choice depends on it)
+    int bm, bn;
+    choose_tile(prec, M, K, bm, bn, taps);
     return bm * 1000 + bn;
 }
 

@@ -383,7 +383,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
                                           1 if out_f32 else 0, _stream()), "seam_conv2d_f16")
     if trace is not None:
         e1.record()
-        tile = lib.seam_conv_tile_prec(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K)
+        tile = lib.seam_conv_tile_taps(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K, pc.R * pc.S)
         if narrow:
             variant = "linear_narrow"
         elif wino24:

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-launch conv efficiency of one config-2 bench step (GPU box): shape, us, TFLOP/s."""
+"""Per-launch conv efficiency of one config-2 bench step (GPU box): shape, us, TFLOP/s.
+usage: conv_breakdown.py [clips per step = 8] [f32 | f16 | bf16x3]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +10,11 @@ import seam_match_rcnn_amd.synth as synth
 
 dev = torch.device("cuda:0")
 model, sd = bench.build_model(dev)
+DT = sys.argv[2] if len(sys.argv) > 2 else "f32"
+if DT == "f16":
+    model.set_compute_dtype(torch.float16)
+elif DT == "bf16x3":
+    model.set_compute_dtype(ops.BX3)
 ta = model.roi_heads.temporal_aggregator
 T, R = bench.WORKLOADS["c2"]["T"], bench.WORKLOADS["c2"]["R"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8          # clips per step
