@@ -104,6 +104,11 @@ int seam_conv2d_dual_f32(const float* x1, const float* x2, const float* w_packed
                          const float* shift, float* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2,
                          int stride2, int K, int relu, seam_stream_t stream);
 
+/* fp16 twin of seam_conv2d_dual_f32 (x1, x2, w_packed, y fp16; C1 and C2 multiples of 64; fp32 accumulation and epilogue). */
+int seam_conv2d_dual_f16(const void* x1, const void* x2, const void* w_packed, const float* scale,
+                         const float* shift, void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2,
+                         int stride2, int K, int relu, seam_stream_t stream);
+
 /* fp16 variant (BASELINE config 5: "fp16 MFMA path with fp32 ... accumulation"): x, w_packed,
  * residual are IEEE fp16 (NHWC, C multiple of 8 and, when C >= 64, of 64); v_mfma_f32_32x32x16_f16
  * with fp32 accumulators; scale/shift stay fp32; y is fp16, or fp32 when y_f32 != 0 (the last trunk
@@ -365,6 +370,7 @@ int seam_linear_narrow_f32(const float* x, const float* w_packed, const float* b
  * can favour F(2x2)). */
 long long seam_wino24_weight_floats(int K, int Cstore);
 long long seam_wino24_issue_slots(int N, int H, int W, int C, int K, int pad);
+int seam_wino24_variant(int N, int H, int W, int C, int K, int pad);   /* n-tiles per block (kernel variant conv3x3_wino24<NT>) picked for this shape; 0 = unsupported */
 long long seam_wino_issue_slots(int N, int H, int W, int C, int K, int pad);
 int seam_pack_conv_weight_wino24_f32(const float* w, float* u_packed, int K, int Cin, int Cstore, int mode,
                                      seam_stream_t stream);

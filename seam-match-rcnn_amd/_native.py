@@ -39,6 +39,7 @@ SIGNATURES = {
     "seam_conv2d_crop_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_s2d_batch_f32": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv2d_dual_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_upres_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_pack_conv_weight_bx3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_bx3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -49,6 +50,7 @@ SIGNATURES = {
     "seam_pack_conv_weight_wino_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "seam_wino_issue_slots": (C.c_longlong, [_i, _i, _i, _i, _i, _i]),
     "seam_wino24_issue_slots": (C.c_longlong, [_i, _i, _i, _i, _i, _i]),
+    "seam_wino24_variant": (_i, [_i, _i, _i, _i, _i, _i]),
     "seam_wino24_weight_floats": (C.c_longlong, [_i, _i]),
     "seam_pack_conv_weight_wino24_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "seam_conv3x3_wino24_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -56,6 +56,7 @@ struct ConvArgs {
     int M;
     int relu;
     int y_f32;         // fp16 kernel only: write fp32 output (descriptor heads stay fp32)
+    int vec_epi;       // fp16 kernel: 16-byte epilogue through the LDS transpose (dev knob SEAM_F16_VEC_EPILOGUE=0 turns it off)
     int slab_bn;       // rows per packed weight slab (128 or 64; fixed at pack time, >= the tile's BN)
     int tiles_m, tiles_n;
     // DUAL kernels (fp32): the reduction runs over TWO 1x1 sources -- chunks [0, C/32) from x [N,Ho,Wo,C] (stride 1) and the rest
@@ -451,6 +452,69 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, eo[k], 0, 0);
+                }
+            }
+            __syncthreads();          // the transpose regions overlap the LDS buffers the next tile's chunk 0 goes to
+        }
+    }
+    if constexpr (F16) {
+        // fp16 output, K % 8 == 0: the same wave-private LDS transpose, a lane owns 8 consecutive output channels -- one 16-byte
+        // residual load and one 16-byte store per 8 outputs instead of eight 2-byte ones (the element-wise form issues 64 scalar
+        // stores per wave and MFMA tile: the 1x1 expansions with K = 256 ... 2048 spent longer in them than in their MFMAs)
+        if (p.vec_epi && !p.y_f32 && (p.K & 7) == 0 && p.rH == 0) {
+            vec_done = true;
+            constexpr int EW = WN + 4;                 // padded row, floats
+            constexpr int LPR = WN / 8;                // lanes per row
+            constexpr int RPI = 64 / LPR;              // rows per 16-byte pass of the wave
+            constexpr int NP = 32 / RPI;               // passes per 32-row MFMA tile
+            float* eb = reinterpret_cast<float*>(BM >= BN ? &As[0][0] : &Bs[0][0]) + wid * 32 * EW;
+            const int er = lq / LPR, ec = (lq % LPR) * 8;
+            const int n = cn0 + wn0 + ec;
+            const bool nok = n < p.K;
+            f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+            if (p.scale && nok) { sc0 = *reinterpret_cast<const f32x4*>(p.scale + n); sc1 = *reinterpret_cast<const f32x4*>(p.scale + n + 4); }
+            if (p.shift && nok) { sh0 = *reinterpret_cast<const f32x4*>(p.shift + n); sh1 = *reinterpret_cast<const f32x4*>(p.shift + n + 4); }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        eb[((r & 3) + 8 * (r >> 2) + 4 * (lq >> 5)) * EW + j * 32 + (lq & 31)] = acc[i][j][r];
+                unsigned eo[NP];
+                f32x4 rv[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int row = wm0 + i * 32 + k * RPI + er;
+                    eo[k] = nok ? (unsigned)(row * p.K + n) * 2u : kOob;
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, eo[k], 0, 0));
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const float* src = &eb[(k * RPI + er) * EW + ec];
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * sc0 + sh0;
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4) * sc1 + sh1;
+                    if (p.res) {
+                        const f16x8 rh = __builtin_bit_cast(f16x8, rv[k]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r0 = (float)rh[e], r1 = (float)rh[e + 4];
+                            v0[e] = p.relu == 2 ? (r0 > 0.f ? v0[e] : 0.f) : v0[e] + r0;
+                            v1[e] = p.relu == 2 ? (r1 > 0.f ? v1[e] : 0.f) : v1[e] + r1;
+                        }
+                    }
+                    if (p.relu == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                    }
+                    f16x8 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hv[e] = (_Float16)v0[e]; hv[e + 4] = (_Float16)v1[e]; }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, eo[k], 0, 0);
                 }
             }
             __syncthreads();          // the transpose regions overlap the LDS buffers the next tile's chunk 0 goes to
@@ -945,11 +1009,13 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.M = N * a.Ho * a.Wo;
     a.relu = relu;
     a.y_f32 = y_f32;
+    static const int vec_epi = getenv("SEAM_F16_VEC_EPILOGUE") ? atoi(getenv("SEAM_F16_VEC_EPILOGUE")) : 1;
+    a.vec_epi = vec_epi;
     a.rH = rH; a.rW = rW;
     a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
     set_row_split(a);
     if (dual) {
-        if (sizeof(T) != 4 || R != 1 || S != 1 || stride != 1 || pad != 0 || (C % BKE) || (dual->C2 % BKE) || dual->stride2 < 1 ||
+        if (R != 1 || S != 1 || stride != 1 || pad != 0 || (C % BKE) || (dual->C2 % BKE) || dual->stride2 < 1 ||
             (a.Ho - 1) * dual->stride2 >= dual->H2 || (a.Wo - 1) * dual->stride2 >= dual->W2 || !dual->x2)
             return (int)hipErrorInvalidValue;
         a.x2 = dual->x2; a.H2 = dual->H2; a.W2 = dual->W2; a.C2 = dual->C2; a.stride2 = dual->stride2;
@@ -971,9 +1037,16 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     const dim3 grid(ntiles < slots ? ntiles : slots);
     static const int dyn = getenv("SEAM_CONV_DYNLDS") ? atoi(getenv("SEAM_CONV_DYNLDS")) : 0;   // dev knob: occupancy experiments
     hipStream_t st = (hipStream_t)stream;
-    if constexpr (sizeof(T) == 4) {
+    {
         if (dual) {
-            if (best_bm == 256) return (int)hipErrorInvalidValue;      // (never chosen for fp32)
+            if (best_bm == 256) {                                      // (fp16 only) the dual form has no 8-wave instance
+                best_bm = 128;
+                a.tiles_m = (a.M + best_bm - 1) / best_bm;
+                const int nt2 = a.tiles_m * a.tiles_n;
+                const dim3 grid2(nt2 < slots4 ? nt2 : slots4);
+                hipLaunchKernelGGL((conv_igemm<T, 128, 128, 4, true>), grid2, dim3(256), dyn, st, a);
+                return (int)hipGetLastError();
+            }
             if (best_bm == 128 && best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 128, 4, true>), grid, dim3(256), dyn, st, a);
             else if (best_bm == 128) hipLaunchKernelGGL((conv_igemm<T, 128, 64, 4, true>), grid, dim3(256), dyn, st, a);
             else if (best_bn == 128) hipLaunchKernelGGL((conv_igemm<T, 64, 128, 4, true>), grid, dim3(256), dyn, st, a);
@@ -1002,6 +1075,7 @@ int conv2d_bx3(const void* x, const void* w_packed, const float* scale, const fl
     a.M = N * a.Ho * a.Wo;
     a.relu = relu;
     a.y_f32 = 1;
+    a.vec_epi = 0;
     a.rH = 0; a.rW = 0;
     a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
     set_row_split(a);
@@ -1072,6 +1146,12 @@ int seam_conv2d_crop_f32(const float* x, const float* w_packed, const float* sca
                          int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int relu, void* stream) {
     if (Ho <= 0 || Wo <= 0) return (int)hipErrorInvalidValue;
     return conv2d<float>(x, w_packed, scale, shift, nullptr, y, N, H, W, C, K, R, S, stride, pad, relu, 1, stream, 0, 0, nullptr, Ho, Wo);
+}
+
+int seam_conv2d_dual_f16(const void* x1, const void* x2, const void* w_packed, const float* scale, const float* shift, void* y,
+                         int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int stride2, int K, int relu, void* stream) {
+    const DualSrc d = {x2, H2, W2, C2, stride2};
+    return conv2d<_Float16>(x1, w_packed, scale, shift, nullptr, y, N, Ho, Wo, C1, K, 1, 1, 1, 0, relu, 0, stream, 0, 0, &d);
 }
 
 int seam_conv2d_dual_f32(const float* x1, const float* x2, const float* w_packed, const float* scale, const float* shift,

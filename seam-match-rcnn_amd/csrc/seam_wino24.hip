@@ -824,6 +824,14 @@ long long seam_wino24_issue_slots(int N, int H, int W, int C, int K, int pad) {
     return (long long)work * a.nt * 32 * 24;
 }
 
+/* n-tiles per block (the kernel's template argument NT = 1 | 2) the launcher picks for this layer shape; 0 = unsupported */
+int seam_wino24_variant(int N, int H, int W, int C, int K, int pad) {
+    Wino24Args a;
+    long blocks;
+    if (wino24_plan(a, N, H, W, C, K, pad, blocks)) return 0;
+    return a.nt;
+}
+
 int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* scale, const float* shift, const float* residual,
                             float* y, int N, int H, int W, int C, int K, int pad, int relu, void* stream) {
     Wino24Args a;

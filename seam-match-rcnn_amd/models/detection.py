@@ -176,9 +176,9 @@ class ResNet50Body(nn.Module):
                         if b.downsample is not None:
                             e["ds"] = ops.pack_conv(b.downsample[0].weight, None, b.downsample[1].tensors(),
                                                     stride=b.stride, bn_eps=b.downsample[1].eps, dtype=dt)
-                            if dt == torch.float32 and FUSE_SHORTCUT:     # conv3 + projection shortcut as one GEMM
+                            if dt in (torch.float32, torch.float16) and FUSE_SHORTCUT:     # conv3 + projection shortcut as one GEMM
                                 e["c3ds"] = ops.pack_conv_dual(b.conv3.weight, b.bn3.tensors(), b.downsample[0].weight,
-                                                               b.downsample[1].tensors(), bn_eps=b.bn3.eps)
+                                                               b.downsample[1].tensors(), bn_eps=b.bn3.eps, dtype=dt)
                         pk[(li, bi)] = e
             self._pk, self._pk_key = pk, key
         return self._pk

@@ -189,6 +189,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
     elif bias is not None:
         shift = bias.contiguous()
     wn = None
+    # (fp32 only: the same kernel on fp16 rows -- 8-byte loads, widened -- measured 1.7 % SLOWER end to end than the 128x64 fp16 tile)
     if (dtype == F32 and mode == 0 and R == 1 and S == 1 and stride == 1 and pad == 0 and scale is None and cs == cin
             and lib.seam_linear_narrow_supported(cs, K)):
         wn = torch.empty((64 * cs,), dtype=F32, device=weight.device)
@@ -339,6 +340,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         if pc.dtype != F32 or residual is not None or out_hw[0] > ho or out_hw[1] > wo:
             raise ValueError("conv2d: out_hw needs exact-fp32 weights, no residual and a size inside the full output")
         ho, wo = int(out_hw[0]), int(out_hw[1])
+    narrow = pc.wn is not None and NARROW and residual is None and out_hw is None
     ydt = F32 if (pc.dtype != F16 or out_f32) else F16
     if out is not None:
         if (not isinstance(out, torch.Tensor) or not out.is_cuda or out.device != x.device or tuple(out.shape) != (n, ho, wo, pc.K)
@@ -354,7 +356,6 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = _native.lib()
-    narrow = pc.wn is not None and NARROW and residual is None and out_hw is None
     wino = pc.dtype == F32 and pc.u is not None and WINOGRAD and out_hw is None and _wino_pays(lib, n, h, w, c, pc.K, pc.pad)
     wino24 = wino and pc.u24 is not None and WINOGRAD24 and _wino24_pays(lib, n, h, w, c, pc.K, pc.pad)
     if narrow:
@@ -387,7 +388,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         if narrow:
             variant = "linear_narrow"
         elif wino24:
-            variant = "conv3x3_wino24"
+            variant = f"conv3x3_wino24<{lib.seam_wino24_variant(n, h, w, c, pc.K, pc.pad)}>"
         elif wino:
             variant = f"conv3x3_wino<{lib.seam_wino_tile_variant(n, h, w, c, pc.K, pc.pad)}>"
         elif pc.dtype == BX3:
@@ -436,7 +437,7 @@ def conv2d_topdown(x: torch.Tensor, pc: PackedConv, top: torch.Tensor) -> torch.
     return y
 
 
-def pack_conv_dual(w1: torch.Tensor, bn1, w2: torch.Tensor, bn2, bn_eps: float = 1e-5) -> PackedConv:
+def pack_conv_dual(w1: torch.Tensor, bn1, w2: torch.Tensor, bn2, bn_eps: float = 1e-5, dtype=F32) -> PackedConv:
     """Weights of ``conv2d_dual``: two 1x1 convs, each followed by its own (Frozen)BatchNorm, summed.
     The scales are folded into the weights (one fp32 rounding per weight) and the shifts added:
     bn_a(W_a . h) + bn_b(W_b . x) = [s_a W_a | s_b W_b] . [h ; x] + (t_a + t_b)."""
@@ -447,37 +448,43 @@ def pack_conv_dual(w1: torch.Tensor, bn1, w2: torch.Tensor, bn2, bn_eps: float =
     wa, ta = fold(w1, bn1)
     wb, tb = fold(w2, bn2)
     w = torch.cat([wa, wb], 1).contiguous()
-    return pack_conv(w[:, :, None, None], (ta + tb).contiguous(), wino=False)
+    return pack_conv(w[:, :, None, None], (ta + tb).contiguous(), wino=False, dtype=dtype)
 
 
 def conv2d_dual(x1: torch.Tensor, x2: torch.Tensor, pc: PackedConv, stride2: int = 1, relu: bool = False) -> torch.Tensor:
-    """y = act(W[:, :C1] . x1 + W[:, C1:] . x2[:, ::stride2, ::stride2] + shift) in ONE launch (``seam_conv2d_dual_f32``):
+    """y = act(W[:, :C1] . x1 + W[:, C1:] . x2[:, ::stride2, ::stride2] + shift) in ONE launch (``seam_conv2d_dual_f32`` / ``_f16``):
     the residual block with a projection shortcut [TV Bottleneck.forward] without writing the shortcut branch to memory.
-    x1 NHWC [N,Ho,Wo,C1], x2 NHWC [N,H2,W2,C2] -> NHWC [N,Ho,Wo,K]; exact fp32."""
+    x1 NHWC [N,Ho,Wo,C1], x2 NHWC [N,H2,W2,C2] -> NHWC [N,Ho,Wo,K]; exact fp32 or fp16 operands (the packed weights' precision)."""
     x1 = _req(x1, None, "x1")
-    x1, x2 = _req(x1, F32, "x1"), _req(x2, F32, "x2")
-    if pc.dtype != F32 or pc.R != 1 or pc.S != 1:
-        raise ValueError("conv2d_dual: needs fp32 1x1 weights from pack_conv_dual")
+    if pc.dtype not in (F32, F16) or pc.R != 1 or pc.S != 1:
+        raise ValueError("conv2d_dual: needs fp32 / fp16 1x1 weights from pack_conv_dual")
+    dt = pc.dtype
+    x1, x2 = _req(x1, dt, "x1"), _req(x2, dt, "x2")
     n, ho, wo, c1 = x1.shape
     n2, h2, w2, c2 = x2.shape
-    if n2 != n or c1 + c2 != pc.Cstore or c1 % 32 or c2 % 32:
-        raise ValueError("conv2d_dual: channel / batch mismatch (C1, C2 must be multiples of 32 and sum to the packed width)")
+    cm = 32 if dt == F32 else 64
+    if n2 != n or c1 + c2 != pc.Cstore or c1 % cm or c2 % cm:
+        raise ValueError(f"conv2d_dual: channel / batch mismatch (C1, C2 must be multiples of {cm} and sum to the packed width)")
     if (ho - 1) * stride2 >= h2 or (wo - 1) * stride2 >= w2:
         raise ValueError("conv2d_dual: x2 too small for the output grid")
-    y = torch.empty((n, ho, wo, pc.K), dtype=F32, device=x1.device)
+    y = torch.empty((n, ho, wo, pc.K), dtype=dt, device=x1.device)
     trace = CONV_TRACE
     if trace is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = _native.lib()
-    _native.check(lib.seam_conv2d_dual_f32(_ptr(x1), _ptr(x2), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, ho, wo, c1,
-                                           h2, w2, c2, stride2, pc.K, int(relu), _stream()), "seam_conv2d_dual_f32")
+    fn = lib.seam_conv2d_dual_f32 if dt == F32 else lib.seam_conv2d_dual_f16
+    _native.check(fn(_ptr(x1), _ptr(x2), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, ho, wo, c1,
+                     h2, w2, c2, stride2, pc.K, int(relu), _stream()), "seam_conv2d_dual")
     if trace is not None:
         e1.record()
-        tile = lib.seam_conv_tile_prec(0, n * ho * wo, pc.K)
-        trace.append((f"conv_igemm<float,{tile // 1000},{tile % 1000}>", 2.0 * n * ho * wo * pc.K * (c1 + c2), e0, e1,
+        tile = lib.seam_conv_tile_prec(0 if dt == F32 else 1, n * ho * wo, pc.K)
+        if tile // 1000 == 256:
+            tile = 128128
+        es = x1.element_size()
+        trace.append((f"conv_igemm<{'float' if dt == F32 else '_Float16'},{tile // 1000},{tile % 1000}>", 2.0 * n * ho * wo * pc.K * (c1 + c2), e0, e1,
                       (n, ho, wo, c1 + c2, pc.K, 1, 1),
-                      float(4 * (x1.numel() + n * ho * wo * c2 + pc.w.numel() + y.numel()))))
+                      float(es * (x1.numel() + n * ho * wo * c2 + pc.w.numel() + y.numel()))))
     return y
 
 

@@ -1,6 +1,8 @@
 """GPU parity of the fp16-MFMA / fp32-accumulate path (BASELINE config 5).  Kernel-level tests feed the
 fp32 oracle the same fp16-rounded operands; the model-level test compares against the fp32 oracle with a
 norm-wise bound that reflects fp16 storage of every activation (2^-11 per rounding, ~50 layers)."""
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -105,3 +107,50 @@ def test_fixed_roi_forward_fp16_vs_fp32_oracle():
     with torch.no_grad():
         res32, feats32, _ = m.forward_fixed_rois([i.to(dev()) for i in imgs], rois)
     assert_close(torch.cat([r["match_features"] for r in res32]), ox3)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 20, 24, 64, 1, 256), (2, 128, 13, 17, 256, 2, 512), (1, 512, 25, 25, 1024, 2, 2048)])
+def test_conv_dual_source_f16(ops, shape):
+    """fp16 twin of the dual-source shortcut GEMM: bn3(conv3(h)) + bn_d(conv_d(x)) + ReLU on fp16 operands, fp32 accumulate.
+    Reference: fp32 on the fp16-rounded activations with the FOLDED weights rounded to fp16 (what the pack stores)."""
+    d = dev()
+    n, c1, ho, wo, c2, s2, k = shape
+    h = rnd(170, (n, c1, ho, wo)).half().float()
+    x = rnd(171, (n, c2, ho * s2 - (s2 - 1), wo * s2 - (s2 - 1))).half().float()
+    w3, wd = rnd(172, (k, c1, 1, 1), "w3") / (c1 ** 0.5), rnd(173, (k, c2, 1, 1), "wd") / (c2 ** 0.5)
+
+    def bn(seed):
+        return (torch.from_numpy(synth.uniform(synth.stream_id(seed, "bw"), (k,), 0.5, 1.5)), rnd(seed + 1, (k,), "bb") * 0.1,
+                rnd(seed + 2, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(seed + 3, "rv"), (k,), 0.5, 1.5)))
+    b3, bd = bn(174), bn(178)
+
+    def fold(w, b):
+        sc = b[0] * (b[3] + 1e-5).rsqrt()
+        return (w * sc[:, None, None, None]).half().float(), b[1] - b[2] * sc
+    w3f, t3 = fold(w3, b3)
+    wdf, td = fold(wd, bd)
+    ref = F.relu(F.conv2d(h, w3f) + F.conv2d(x, wdf, None, s2) + (t3 + td)[None, :, None, None])
+    pc = ops.pack_conv_dual(w3.to(d), tuple(t.to(d) for t in b3), wd.to(d), tuple(t.to(d) for t in bd), dtype=H)
+    got = ops.conv2d_dual(nhwc(h).half().to(d), nhwc(x).half().to(d), pc, s2, relu=True)
+    assert got.dtype == H
+    assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
+
+
+def test_vector_epilogue_f16_tails_and_residual(ops):
+    """The 16-byte fp16 epilogue (K % 8 == 0) on ragged row counts and K that is not a multiple of the tile width, with
+    residual + ReLU, against the element-wise epilogue's contract (fp32 oracle on fp16-rounded operands)."""
+    d = dev()
+    for seed, (n, c, hh, ww, k, res) in enumerate([(1, 64, 9, 11, 72, True), (2, 128, 5, 7, 200, False), (1, 256, 33, 3, 1024, True),
+                                                  (3, 64, 1, 1, 8, True)]):
+        x = rnd(190 + seed, (n, c, hh, ww)).half().float()
+        wt = (rnd(195 + seed, (k, c, 1, 1), "w") / math.sqrt(c)).half().float()
+        bias = rnd(199 + seed, (k,), "b") * 0.1
+        ref = F.conv2d(x, wt, bias)
+        resid = rnd(205 + seed, ref.shape, "r").half().float() if res else None
+        if res:
+            ref = ref + resid
+        ref = F.relu(ref)
+        pc = ops.pack_conv(wt.to(d), bias.to(d), dtype=H)
+        y = ops.conv2d(nhwc(x).half().to(d), pc, True, None if resid is None else nhwc(resid).half().to(d))
+        assert y.dtype == H
+        assert_close(y.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)

@@ -23,7 +23,8 @@ for i in range($i):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0.0]))
     for r in csv.DictReader(open(f)):
         if "conv3x3_wino24" in r["Kernel_Name"]:
-            key = "conv3x3_wino24"
+            mm = re.search(r"conv3x3_wino24<(\d+)>", r["Kernel_Name"])
+            key = f"conv3x3_wino24<{mm.group(1)}>" if mm else "conv3x3_wino24"
             a = agg[r["Counter_Name"]][key]
             a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             continue
