@@ -369,27 +369,41 @@ def batched_nms(boxes, scores, idxs, thr, top_n: int = 0):
     return order[keep.bool()]
 
 
-def batched_nms_images(boxes, scores, idxs, valid, thr, top_n):
+def batched_nms_images(boxes, scores, idxs, valid, thr, top_n, prefix: int = 0):
     """``batched_nms`` for a whole batch of images in one set of launches.
 
     boxes [B,n,4], scores [B,n], idxs [B,n] (class / level id), valid [B,n] bool (entries removed by
     the score / small-box filters).  Per image: offset boxes by idx*(max_coord+1) (max over the
     image's valid boxes, as torchvision computes it on the filtered set), sort by score (stable,
     descending), greedy NMS, keep the first ``top_n`` survivors (the scan kernel stops there).
+
+    prefix > 0: only the ``prefix`` best-scored candidates of each image enter the IoU matrix (its workspace and work grow
+    with the square of that number).  Greedy NMS decides a box from higher-scored boxes only, so the result is EXACT for an
+    image whenever the prefix already holds ``top_n`` survivors or every valid candidate; ``exact`` says so per image and the
+    caller repeats the call without a prefix in the (rare) other case.
+
     -> (order [B,n] int64: candidate index at each sorted position, sel [B,n] bool: sorted positions
-    that survive).  No host synchronisation."""
+    that survive, exact [B] bool).  No host synchronisation."""
+    n = boxes.shape[1]
     neg = torch.finfo(boxes.dtype).min
     mx = torch.where(valid[..., None], boxes, boxes.new_full((), neg)).amax(dim=(1, 2))            # [B]
     off = idxs.to(boxes) * (mx[:, None] + 1.0)
     sc = torch.where(valid, scores, scores.new_full((), -1.0))                                      # invalid sort last
     order = torch.argsort(sc, dim=1, descending=True, stable=True)
-    sb = torch.gather(boxes + off[..., None], 1, order[..., None].expand(-1, -1, 4))
-    sv = torch.gather(valid, 1, order)
+    m = n if prefix <= 0 else min(n, int(prefix))
+    head = order[:, :m]
+    sb = torch.gather(boxes + off[..., None], 1, head[..., None].expand(-1, -1, 4))
+    sv = torch.gather(valid, 1, head)
     # invalid entries become far-away degenerate boxes: they suppress nothing, sort behind every valid entry (so the scan's
     # survivor count reaches them only after all valid survivors were counted) and are masked out below
     sb = torch.where(sv[..., None], sb, sb.new_full((), -1.0e8)).contiguous()
     keep = ops.nms_sorted(sb, thr, max_keep=int(top_n)).bool() & sv
-    return order, keep
+    if m == n:
+        return order, keep, torch.ones((boxes.shape[0],), dtype=torch.bool, device=boxes.device)
+    exact = (keep.sum(1) >= int(top_n)) | (valid.sum(1) <= m)
+    full = torch.zeros((boxes.shape[0], n), dtype=torch.bool, device=boxes.device)
+    full[:, :m] = keep
+    return order, full, exact
 
 
 class RegionProposalNetwork(nn.Module):
@@ -438,7 +452,7 @@ class RegionProposalNetwork(nn.Module):
         else:
             bx, sc, lv = self._topk_by_sort(self.head(fl), anchors, image_sizes, ks, n, dev)
         valid = ((bx[..., 2] - bx[..., 0]) >= self.min_size) & ((bx[..., 3] - bx[..., 1]) >= self.min_size)
-        order, sel = batched_nms_images(bx, sc, lv, valid, self.nms_thresh, self.post_nms_top_n)
+        order, sel, _ = batched_nms_images(bx, sc, lv, valid, self.nms_thresh, self.post_nms_top_n)
         kept = torch.gather(bx, 1, order[..., None].expand(-1, -1, 4))
         counts = sel.sum(1).tolist()                                                    # the one sync
         return list(kept[sel].split(counts, 0))

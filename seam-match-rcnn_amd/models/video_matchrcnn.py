@@ -37,6 +37,7 @@ class TemporalRoIHeads(nn.Module):
 
     video = True                    # emit 'roi_features' (ref :314); NewRoIHeads does not
     roi_features_contiguous = False  # True: 'roi_features' as a contiguous NCHW copy instead of a channels_last view
+    nms_prefix = 4096                # candidates per image that enter the detection NMS (exactness is checked, see postprocess_detections)
     fallback_score = 0.1            # ref :252 (1.0 in models/matchrcnn.py:377)
 
     def __init__(self, num_classes=91, n_frames=3, box_score_thresh=0.05, box_nms_thresh=0.5,
@@ -84,8 +85,6 @@ class TemporalRoIHeads(nn.Module):
         # pad every image to the same number of proposals so the whole batch is filtered at once
         pmax = max(counts)
         c = (num_classes - 1) * pmax
-        if c > 16384:       # beyond the batched NMS kernel's per-image capacity (e.g. 91 classes): per-image path
-            return self._postprocess_per_image(boxes.view(-1, num_classes, 4), pred_scores, counts)
         pb = boxes.new_zeros((n_img, pmax, num_classes, 4))
         ps = pred_scores.new_full((n_img, pmax, num_classes), -1.0)
         row = torch.cat([torch.arange(k, device=dev) for k in counts])
@@ -95,10 +94,21 @@ class TemporalRoIHeads(nn.Module):
         pb, ps = pb[:, :, 1:].reshape(n_img, c, 4), ps[:, :, 1:].reshape(n_img, c)           # drop background
         labels = torch.arange(1, num_classes, device=dev).repeat(pmax)[None].expand(n_img, -1)
         valid = (ps > self.score_thresh) & ((pb[..., 2] - pb[..., 0]) >= 1e-2) & ((pb[..., 3] - pb[..., 1]) >= 1e-2)
-        order, sel = det.batched_nms_images(pb, ps, labels, valid, self.nms_thresh, self.detections_per_img)
+        # Only the NMS_PREFIX best-scored candidates of an image enter the IoU matrix (13 classes x 1000 proposals = 13 000 padded
+        # candidates would cost a 21 MB bit matrix per image for 100 detections).  Exact whenever the prefix holds
+        # detections_per_img survivors or all valid candidates -- checked on the device and read back with the counts (the one
+        # sync); otherwise the call is repeated on everything, or per image when that exceeds the kernel's capacity.
+        prefix = self.nms_prefix if c > self.nms_prefix else 0
+        order, sel, exact = det.batched_nms_images(pb, ps, labels, valid, self.nms_thresh, self.detections_per_img, prefix)
+        stats = torch.cat([sel.sum(1), exact.to(torch.int64)]).tolist()                      # one sync
+        if not all(stats[n_img:]):
+            if c > det.NMS_MAX_BOXES:       # beyond the batched NMS kernel's per-image capacity (e.g. 91 classes): per-image path
+                return self._postprocess_per_image(boxes.view(-1, num_classes, 4), pred_scores, counts)
+            order, sel, _ = det.batched_nms_images(pb, ps, labels, valid, self.nms_thresh, self.detections_per_img)
+            stats = sel.sum(1).tolist()
+        kept = stats[:n_img]
         kb = torch.gather(pb, 1, order[..., None].expand(-1, -1, 4))
         ks, kl = torch.gather(ps, 1, order), torch.gather(labels, 1, order)
-        kept = sel.sum(1).tolist()                                                           # one sync
         return (list(kb[sel].split(kept, 0)), list(ks[sel].split(kept, 0)), list(kl[sel].split(kept, 0)))
 
     def _postprocess_per_image(self, boxes, scores, counts):

@@ -391,7 +391,18 @@ def test_batched_nms_and_paste_masks(ops):
     cls = (torch.from_numpy(synth.uniform(synth.stream_id(83, "l"), (b, n))) * 5).to(torch.int64)
     valid = scores > 0.2
     valid[1, ::7] = False
-    order, sel = batched_nms_images(boxes.to(d), scores.to(d), cls.to(d), valid.to(d), 0.5, 100)
+    order, sel, exact = batched_nms_images(boxes.to(d), scores.to(d), cls.to(d), valid.to(d), 0.5, 100)
+    assert bool(exact.all())
+    # prefix form: with a prefix that reaches each image's last survivor the selection equals the full call's, and wherever
+    # the call reports `exact` the prefix really held 100 survivors (or every valid candidate)
+    last = int(max(int(torch.nonzero(sel[i]).max()) for i in range(b))) + 1
+    order_p, sel_p, exact_p = batched_nms_images(boxes.to(d), scores.to(d), cls.to(d), valid.to(d), 0.5, 100, prefix=last)
+    assert torch.equal(order_p, order) and torch.equal(sel_p, sel)
+    for i in range(b):
+        assert bool(exact_p[i]) == (int(sel[i].sum()) >= 100 or int(valid[i].sum()) <= last)
+    # a prefix too short to hold 100 survivors that does not cover the valid candidates must say so
+    _, sel_s, exact_s = batched_nms_images(boxes.to(d), scores.to(d), cls.to(d), valid.to(d), 0.5, 100, prefix=8)
+    assert not bool(exact_s.any()) and int(sel_s[:, 8:].sum()) == 0
     for i in range(b):
         v = valid[i]
         ref = OD.batched_nms(boxes[i][v], scores[i][v], cls[i][v], 0.5)[:100]
