@@ -88,7 +88,7 @@ __device__ __forceinline__ void split_row(const ConvArgs& p, int HoWo, int rl, i
     }
 }
 
-// Measured and not kept (round 2, gpurun_out/r02j_f16_wave128.txt): the fp16 256 x 128 tile as 4 waves of 128 x 64 (0.75 LDS fragment
+// Measured and not kept (round 2, profiles/r02_f16_wave128.txt): the fp16 256 x 128 tile as 4 waves of 128 x 64 (0.75 LDS fragment
 // reads per MFMA instead of 1, 128 accumulators, one block of 4 waves per CU) runs 763 TFLOP/s on the 80 x 200^2 x 256 -> 256 layer
 // against 859 for the same tile as 8 waves of 64 x 64: the 16-bit kernels are bound by load latency, not by LDS bandwidth, and four
 // waves per CU hide less of it.
@@ -948,7 +948,7 @@ inline int tile_weight(int prec, int bm, int bn, int taps) {
     const int area = bm * bn;
     if (prec == P_F32) return area == 256 * 128 ? 100 : area == 128 * 128 ? 100 : area == 64 * 64 ? 125 : 110;
     // fp16: the 256 x 128 / 8-wave tile wins on the 3x3 layers (859 vs 752 TFLOP/s at 80 x 200^2 x 256 -> 256, +3-5 % at 100^2 and on
-    // the 14 x 14 ROI maps) and loses 3-5 % on the 1x1 layers (gpurun_out/r02j_f16_wave128.txt)
+    // the 14 x 14 ROI maps) and loses 3-5 % on the 1x1 layers (profiles/r02_f16_wave128.txt)
     if (prec == P_F16 && area == 256 * 128) return taps >= 9 ? 92 : 105;
     return area == 256 * 128 ? 95 : area == 128 * 128 ? 100 : area == 64 * 64 ? 200 : 150;
 }

@@ -57,7 +57,7 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 #endif
 // The input transform's VALU work sits between fp32 MFMAs.  MI355X_MICROARCH.md lists packed fp32 VALU instructions as an
 // anti-lever beside (bf16) MFMAs; beside FP32 MFMAs that does not hold -- measured on the bench's twelve layer shapes
-// (gpurun_out/r02g_w24_scalar_valu.txt, one box): the scalar-lane form (72 v_fma/add/sub per chunk, SEAM_W24_PK=0) is 1-2 % SLOWER
+// (profiles/r02_w24_scalar_valu.txt, one box): the scalar-lane form (72 v_fma/add/sub per chunk, SEAM_W24_PK=0) is 1-2 % SLOWER
 // than the packed form (36 v_pk_*): the fp32 MFMA and the fp32 VALU share the SIMD's FMA lanes, what counts is FMAs, not opcodes.
 __device__ __forceinline__ float s_fma(float c, float b, float a) {        // a + c * b, c wave-uniform (SGPR)
     float d;
