@@ -221,6 +221,21 @@ int seam_nlb_attnpool_f32(const float* seq, int64_t t_stride, int64_t s_stride, 
                           const float* w_att, const float* b_att, float* out, float* att,
                           float* z, float* ws, int use_nlb, seam_stream_t stream);
 
+/* The same block with its GEMMs on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32): G = X Wg + bg, Y = f G and
+ * Z = Y Ww^T + bw + X per 32-row tile, one workgroup per sequence, sequences of at most seam_nlb_mfma_max_len() (96) rows;
+ * seq rows 16-byte aligned (t_stride, s_stride multiples of 4 floats).  theta / phi enter the block only through
+ * a_i = theta_i . wc[:128] and b_j = phi_j . wc[128:] (models/nlb.py:80-90), so the caller folds them once:
+ *   u[256] = W_theta^T wc[:128], v[256] = W_phi^T wc[128:], cd[2] = (b_theta . wc[:128], b_phi . wc[128:]).
+ * wg_frag [4][32][64][4] / wo_frag [8][16][64][4]: the g and W projections in MFMA B-fragment order -- element e of lane
+ * (h = lane >> 5, n = lane & 31) of fragment [n_tile][j] = W[k = 8 j + 4 h + e][32 n_tile + n] (W as [k][n]).
+ * out / att / z / use_nlb as above. */
+int seam_nlb_mfma_max_len(void);
+int seam_nlb_attnpool_mfma_f32(const float* seq, int64_t t_stride, int64_t s_stride, const int* len, int S, int Tmax,
+                               const float* wg_frag, const float* b_g, const float* u, const float* v,
+                               const float* cd, const float* wo_frag, const float* b_out, const float* w_att,
+                               const float* b_att, float* out, float* att, float* z, int use_nlb,
+                               seam_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Pairwise match classifier `last((a_i - b_j)^2)`: models/match_head.py:73-74,161-162;
  * NumPy twin evaluate_movingfashion.py:94-100,263-264.

@@ -78,6 +78,8 @@ SIGNATURES = {
     "seam_avgpool_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "seam_nlb_workspace_floats": (_i64, [_i, _i]),
     "seam_nlb_attnpool_f32": (_i, [_p, _i64, _i64, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "seam_nlb_mfma_max_len": (_i, []),
+    "seam_nlb_attnpool_mfma_f32": (_i, [_p, _i64, _i64, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "seam_pair_logits_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "seam_rank_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "seam_match_scores_f32": (_i, [_p, _p, _i64, _p]),

@@ -195,6 +195,236 @@ __global__ __launch_bounds__(256) void nlb_attnpool_kernel(const NlbArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same block with its GEMMs on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32), one workgroup (4 waves) per
+// sequence, rows in tiles of 32 (sequences up to NLB_TMF = 96 rows; longer ones take the kernel above):
+//   G  = X Wg + bg            [32 x 256] x [256 x 128]   wave w -> output columns 32 w .. 32 w + 31
+//   Y  = f G, f_ij = relu(a_i + b_j) / T   [32 x T] x [T x 128]   A fragments (f) are made in registers from a_i, b_j
+//   Z  = Y Ww^T + bw + X      [32 x 128] x [128 x 256]   wave w -> columns 64 w .. 64 w + 63
+// theta / phi enter the block only through a_i = theta_i . wc[:128] and b_j = phi_j . wc[128:] (the concat_project weight),
+// so the two 256 -> 128 projections collapse to two 256-vectors u = W_theta^T wc[:128], v = W_phi^T wc[128:] (folded once
+// at pack time in fp64) and a_i = X_i . u + c: a third of the block's FLOPs instead of three quarters of them.
+// Weights arrive in MFMA B-fragment order ([n_tile][k / 8][lane][4], element e of lane (h = lane >> 5, n = lane & 31)
+// = W[k = 8 j + 4 h + e][n]): a wave streams them with one coalesced 1 KiB load per four MFMAs; A fragments are 16-byte
+// LDS reads of row-major tiles with an odd 16-byte-slot pitch (conflict-free), using the same k pairing {e, e + 4}.
+constexpr int NLB_TMF = 96;
+constexpr int XLD = 260, GLD = 132, YLD = 132;          // LDS pitches (floats): 65 / 33 / 33 sixteen-byte slots, odd
+
+struct NlbMfArgs {
+    const float* seq;
+    int64_t t_stride, s_stride;
+    const int* len;
+    int S, Tmax;
+    const float* wg_frag;    // [4][32][64][4]   G projection, fragment order
+    const float* b_g;        // [128]
+    const float* u;          // [256]  W_theta^T wc[:128]
+    const float* v;          // [256]  W_phi^T   wc[128:]
+    const float* cd;         // [2]    b_theta . wc[:128],  b_phi . wc[128:]
+    const float* wo_frag;    // [8][16][64][4]   W (output) projection, fragment order
+    const float* b_out;      // [256]
+    const float* w_att;      // [256]
+    const float* b_att;      // [1]
+    float* out;              // [S][256]
+    float* att;              // [S][Tmax] or null
+    float* z;                // [S][Tmax][256] or null
+    int use_nlb;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void nlb_attnpool_mfma_kernel(const NlbMfArgs p) {
+    __shared__ __attribute__((aligned(16))) float Xs[32 * XLD];
+    __shared__ __attribute__((aligned(16))) float Gs[NLB_TMF * GLD];
+    __shared__ __attribute__((aligned(16))) float Ys[32 * YLD];
+    __shared__ float av[NLB_TMF], bv[NLB_TMF], red[32 * 4], scs[32];
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int nl = lane & 31, h = lane >> 5;
+    const int T = p.len[s];
+    const float* X = p.seq + (int64_t)s * p.s_stride;
+    float* outp = p.out + (size_t)s * D;
+    if (T <= 0) { outp[tid] = 0.f; return; }
+    const bool nlb = p.use_nlb == 2 || (p.use_nlb && T > 1);   // 2 = apply even to a single row
+    const int ntile = (T + 31) >> 5;
+
+    auto load_x_tile = [&](int r0) {       // rows r0 .. r0 + 31 of X -> Xs (zeros past the end); 8 x 16 bytes per thread
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = w + 4 * i, c4 = lane;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (r0 + row < T) x = *reinterpret_cast<const f32x4*>(X + (int64_t)(r0 + row) * p.t_stride + c4 * 4);
+            *reinterpret_cast<f32x4*>(&Xs[row * XLD + c4 * 4]) = x;
+        }
+    };
+
+    if (nlb) {
+        // ---- phase 1: a, b and G for every row -------------------------------------------------------------------
+        const f32x4 u4 = *reinterpret_cast<const f32x4*>(p.u + lane * 4), v4 = *reinterpret_cast<const f32x4*>(p.v + lane * 4);
+        const float c0 = p.cd[0], d0 = p.cd[1];
+        const float bg = p.b_g[32 * w + nl];
+        for (int t = 0; t < ntile; ++t) {
+            const int r0 = 32 * t;
+            __syncthreads();                       // readers of the previous tile's Xs are done
+            load_x_tile(r0);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {          // wave w: rows 8 w .. 8 w + 7
+                const int row = 8 * w + i;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&Xs[row * XLD + lane * 4]);
+                const float pa = wave_sum(x[0] * u4[0] + x[1] * u4[1] + x[2] * u4[2] + x[3] * u4[3]);
+                const float pb = wave_sum(x[0] * v4[0] + x[1] * v4[1] + x[2] * v4[2] + x[3] * v4[3]);
+                if (lane == 0 && r0 + row < NLB_TMF) { av[r0 + row] = pa + c0; bv[r0 + row] = pb + d0; }
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const f32x4* bf = reinterpret_cast<const f32x4*>(p.wg_frag) + (size_t)w * 32 * 64 + lane;
+#pragma unroll 4
+            for (int j = 0; j < 32; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&Xs[nl * XLD + 8 * j + 4 * h]);
+                const f32x4 b = bf[j * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < NLB_TMF) Gs[row * GLD + 32 * w + nl] = acc[r] + bg;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: Y = f G ; Z = Y Ww^T + bw + X ; online-softmax attention pooling --------------------------------
+    const int col0 = 64 * w + nl, col1 = col0 + 32;      // this lane's two output columns (C layout: col = lane & 31 per n-tile)
+    const float wa0 = p.w_att[col0], wa1 = p.w_att[col1];
+    const float bo0 = p.b_out[col0], bo1 = p.b_out[col1];
+    const float ba = p.b_att[0];
+    const float inv_t = 1.f / (float)T;
+    float m_run = -INFINITY, l_run = 0.f, o0 = 0.f, o1 = 0.f;
+    const int kpad = (T + 7) & ~7;
+    for (int t = 0; t < ntile; ++t) {
+        const int r0 = 32 * t;
+        const int nr = min(32, T - r0);
+        if (!(nlb && ntile == 1)) {                // (one-tile sequences still hold their X tile from phase 1)
+            __syncthreads();
+            load_x_tile(r0);
+        }
+        float z0[16], z1[16];
+        if (nlb) {
+            {   // Y tile: wave w -> columns 32 w .. 32 w + 31
+                const float ai = av[min(r0 + nl, NLB_TMF - 1)];
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int jj = 0; jj < kpad; jj += 8) {
+                    f32x4 a, b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = jj + 4 * h + e;
+                        const bool ok = k < T;
+                        a[e] = ok ? fmaxf(ai + bv[ok ? k : 0], 0.f) * inv_t : 0.f;
+                        b[e] = ok ? Gs[k * GLD + 32 * w + nl] : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+                }
+                __syncthreads();                   // previous tile's readers of Ys are done; Xs of this tile is complete
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Ys[((r & 3) + 8 * (r >> 2) + 4 * h) * YLD + 32 * w + nl] = acc[r];
+                __syncthreads();
+            }
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            const f32x4* bf = reinterpret_cast<const f32x4*>(p.wo_frag) + (size_t)(2 * w) * 16 * 64 + lane;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&Ys[nl * YLD + 8 * j + 4 * h]);
+                const f32x4 b0 = bf[j * 64], b1 = bf[(16 + j) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b0[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b1[e], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool ok = row < nr;
+                z0[r] = ok ? acc0[r] + bo0 + Xs[row * XLD + col0] : 0.f;
+                z1[r] = ok ? acc1[r] + bo1 + Xs[row * XLD + col1] : 0.f;
+            }
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool ok = row < nr;
+                z0[r] = ok ? Xs[row * XLD + col0] : 0.f;
+                z1[r] = ok ? Xs[row * XLD + col1] : 0.f;
+            }
+        }
+        if (p.z) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < nr) {
+                    float* q = p.z + ((size_t)s * p.Tmax + r0 + row) * D;
+                    q[col0] = z0[r];
+                    q[col1] = z1[r];
+                }
+            }
+        }
+        // scores s_row = Z_row . wa + ba: a lane holds 2 of a row's 256 columns; reduce over the 32 lanes of its half,
+        // then over the 4 waves through LDS
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = z0[r] * wa0 + z1[r] * wa1;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (nl == 0) red[((r & 3) + 8 * (r >> 2) + 4 * h) * 4 + w] = v;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const float sv = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3] + ba;
+            scs[tid] = sv;
+            if (p.att && tid < nr) p.att[(size_t)s * p.Tmax + r0 + tid] = sv;   // raw score, normalised below
+        }
+        __syncthreads();
+        float m_new = m_run;
+        for (int r = 0; r < nr; ++r) m_new = fmaxf(m_new, scs[r]);
+        const float corr = expf(m_run - m_new);     // exp(-inf) = 0 on the first tile
+        l_run *= corr;
+        o0 *= corr;
+        o1 *= corr;
+        for (int r = 0; r < nr; ++r) l_run += expf(scs[r] - m_new);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float e = row < nr ? expf(scs[row] - m_new) : 0.f;
+            o0 = fmaf(e, z0[r], o0);
+            o1 = fmaf(e, z1[r], o1);
+        }
+        m_run = m_new;
+    }
+    o0 += __shfl_xor(o0, 32, 64);                   // the two row halves of the C layout
+    o1 += __shfl_xor(o1, 32, 64);
+    if (h == 0) {
+        outp[col0] = o0 / l_run;
+        outp[col1] = o1 / l_run;
+    }
+    if (p.att) {
+        __syncthreads();
+        for (int t = tid; t < T; t += 256) {
+            float* q = p.att + (size_t)s * p.Tmax + t;
+            *q = expf(*q - m_run) / l_run;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pair logits: block tile (8*QT) x (32*GT) pairs, thread tile QT x GT, k chunks of 32 through LDS.
 // The two classes of a pair live in one float2 so the inner loop is packed fp32 math
 // (v_pk_add / v_pk_mul / v_pk_fma: the fp32 vector peak needs the packed forms): per k and per
@@ -616,6 +846,22 @@ int seam_nlb_attnpool_f32(const float* seq, int64_t t_stride, int64_t s_stride, 
     a.w_att = w_att; a.b_att = b_att; a.out = out; a.att = att; a.z = z; a.ws = ws; a.use_nlb = use_nlb;
     const size_t lds = (size_t)(RC * D + RC * DI + RC * 4 + RC + T_LDS * DI + 2 * T_LDS) * sizeof(float);
     hipLaunchKernelGGL(nlb_attnpool_kernel, dim3(S), dim3(256), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int seam_nlb_mfma_max_len(void) { return NLB_TMF; }
+
+int seam_nlb_attnpool_mfma_f32(const float* seq, int64_t t_stride, int64_t s_stride, const int* len, int S, int Tmax,
+                               const float* wg_frag, const float* b_g, const float* u, const float* v, const float* cd,
+                               const float* wo_frag, const float* b_out, const float* w_att, const float* b_att, float* out,
+                               float* att, float* z, int use_nlb, void* stream) {
+    if (S <= 0) return 0;
+    if (Tmax > NLB_TMF || (t_stride & 3) || (s_stride & 3) || ((uintptr_t)seq & 15)) return (int)hipErrorInvalidValue;
+    NlbMfArgs a;
+    a.seq = seq; a.t_stride = t_stride; a.s_stride = s_stride; a.len = len; a.S = S; a.Tmax = Tmax;
+    a.wg_frag = wg_frag; a.b_g = b_g; a.u = u; a.v = v; a.cd = cd; a.wo_frag = wo_frag; a.b_out = b_out;
+    a.w_att = w_att; a.b_att = b_att; a.out = out; a.att = att; a.z = z; a.use_nlb = use_nlb;
+    hipLaunchKernelGGL(nlb_attnpool_mfma_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

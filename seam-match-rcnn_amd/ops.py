@@ -669,10 +669,34 @@ class PackedNLB:
     b_att: torch.Tensor      # [1]
 
 
+NLB_MFMA = _os.environ.get("SEAM_NLB_MFMA", "1") != "0"      # 0: the VALU form of the block for every sequence length
+
+
+def _nlb_mfma_pack(pk: PackedNLB):
+    """Weights of ``seam_nlb_attnpool_mfma_f32`` derived (once per PackedNLB) from the plain pack:
+    MFMA B-fragment order of the g and W projections -- element e of lane (h = lane >> 5, n = lane & 31) of fragment
+    [n_tile][k / 8] is W[k = 8 j + 4 h + e][32 n_tile + n] -- and the folded theta / phi projections: theta and phi enter the
+    block only through a_i = theta_i . wc[:128], b_j = phi_j . wc[128:] (ref models/nlb.py:80-90), i.e. a_i = X_i . u + c with
+    u = W_theta^T wc[:128] (folded in fp64, rounded once)."""
+    m = getattr(pk, "_mfma", None)
+    if m is None:
+        wp, bp, wc = pk.w_proj_t.double(), pk.b_proj.double(), pk.w_cat.double()       # [256,384], [384], [256]
+        u = (wp[:, :128] @ wc[:128]).float().contiguous()
+        v = (wp[:, 128:256] @ wc[128:]).float().contiguous()
+        cd = torch.stack([bp[:128] @ wc[:128], bp[128:256] @ wc[128:]]).float().contiguous()
+        wg = pk.w_proj_t[:, 256:]                                                        # [256 k, 128 n]
+        wg_frag = wg.reshape(32, 2, 4, 4, 32).permute(3, 0, 1, 4, 2).contiguous()       # [nt, j, h, n, e]
+        wo_frag = pk.w_out_t.reshape(16, 2, 4, 8, 32).permute(3, 0, 1, 4, 2).contiguous()   # [128 k, 256 n] -> [nt, j, h, n, e]
+        m = pk._mfma = (wg_frag, pk.b_proj[256:].contiguous(), u, v, cd, wo_frag)
+    return m
+
+
 def nlb_attnpool(seq: torch.Tensor, t_stride: int, s_stride: int, lens: torch.Tensor, n_seq: int, t_max: int,
                  pk: PackedNLB, use_nlb: bool = True, want_att: bool = False, want_z: bool = False):
     """Batched non-local block + attention pooling.
-    Returns (out[S,256], att[S,Tmax] | None) and additionally z[S,Tmax,256] when want_z."""
+    Returns (out[S,256], att[S,Tmax] | None) and additionally z[S,Tmax,256] when want_z.
+    Sequences of up to ``seam_nlb_mfma_max_len()`` (96) rows run the block's GEMMs on the matrix cores
+    (``seam_nlb_attnpool_mfma_f32``); longer ones take the VALU kernel with its global scratch."""
     lib = _native.lib()
     seq = _req(seq, name="seq")
     lens = _req(lens, torch.int32, "lens")
@@ -680,6 +704,14 @@ def nlb_attnpool(seq: torch.Tensor, t_stride: int, s_stride: int, lens: torch.Te
     att = torch.zeros((n_seq, t_max), dtype=F32, device=seq.device) if want_att else None
     z = torch.zeros((n_seq, t_max, 256), dtype=F32, device=seq.device) if want_z else None
     if n_seq == 0:
+        return (out, att, z) if want_z else (out, att)
+    if (NLB_MFMA and t_max <= int(lib.seam_nlb_mfma_max_len()) and t_stride % 4 == 0 and s_stride % 4 == 0
+            and seq.data_ptr() % 16 == 0):
+        wg_frag, b_g, u, v, cd, wo_frag = _nlb_mfma_pack(pk)
+        _native.check(lib.seam_nlb_attnpool_mfma_f32(_ptr(seq), t_stride, s_stride, _ptr(lens), n_seq, t_max, _ptr(wg_frag), _ptr(b_g),
+                                                     _ptr(u), _ptr(v), _ptr(cd), _ptr(wo_frag), _ptr(pk.b_out), _ptr(pk.w_att),
+                                                     _ptr(pk.b_att), _ptr(out), _ptr(att), _ptr(z), int(use_nlb), _stream()),
+                      "seam_nlb_attnpool_mfma_f32")
         return (out, att, z) if want_z else (out, att)
     ws = torch.empty((int(lib.seam_nlb_workspace_floats(n_seq, t_max)),), dtype=F32, device=seq.device)
     _native.check(lib.seam_nlb_attnpool_f32(_ptr(seq), t_stride, s_stride, _ptr(lens), n_seq, t_max, _ptr(pk.w_proj_t),

@@ -321,6 +321,54 @@ def test_nlb_attnpool_golden_and_oracle(ops, golden):
         assert_close(att2[i, :n], atts[0][:, 0])
 
 
+def test_nlb_attnpool_mfma_vs_valu_and_oracle(ops):
+    """The matrix-core form of the block (G = X Wg, Y = f G, Z = Y Ww^T on v_mfma_f32_32x32x2_f32, theta / phi folded into two
+    256-vectors) against the VALU kernel and the oracle: every row-tile boundary (1 ... 96 rows), both memory layouts
+    (sequence-major and the reference's time-major x3_1_seq), z / attention outputs, use_nlb = 0 / 1 / 2."""
+    d = dev()
+    from seam_match_rcnn_amd.models.match_head import pack_nlb_from_state
+    p = to_torch(synth.temporal_aggregator_state(12))
+    pk = pack_nlb_from_state({k: v.to(d) for k, v in p.items()})
+    lens = [1, 2, 7, 10, 31, 32, 33, 63, 64, 65, 95, 96, 0, 30]
+    tmax = max(lens)
+    assert tmax <= ops._native.lib().seam_nlb_mfma_max_len()
+    x = rnd(51, (len(lens), tmax, 256), "mf")
+    ld = torch.tensor(lens, dtype=torch.int32, device=d)
+    for use in (1, 2, 0):
+        res = {}
+        for flag in (True, False):
+            ops.NLB_MFMA = flag
+            try:
+                res[flag] = ops.nlb_attnpool(x.to(d), 256, tmax * 256, ld, len(lens), tmax, pk, use, True, True)
+            finally:
+                ops.NLB_MFMA = True
+        (o1, a1, z1), (o0, a0, z0) = res[True], res[False]
+        assert_close(o1, o0, rtol=1e-4, atol_scale=1e-5)
+        assert_close(a1, a0, rtol=1e-4, atol_scale=1e-5)
+        assert_close(z1, z0, rtol=1e-4, atol_scale=1e-5)
+        if use == 1:
+            for i, n in enumerate(lens):
+                if n == 0:
+                    assert float(o1[i].abs().max()) == 0.0
+                    continue
+                ref, atts = OH.aggregate_sequences([x[i, :n]], p)
+                assert_close(o1[i], ref[0])
+                assert_close(a1[i, :n], atts[0][:, 0])
+    # time-major layout [T, S, 256] (what TemporalAggregationNLB hands over): t_stride = S*256, s_stride = 256
+    s_, t_ = 37, 10
+    xt = rnd(52, (t_, s_, 256), "tm")
+    lt = torch.tensor([(i % t_) + 1 for i in range(s_)], dtype=torch.int32, device=d)
+    o1, _ = ops.nlb_attnpool(xt.to(d), s_ * 256, 256, lt, s_, t_, pk)
+    ops.NLB_MFMA = False
+    try:
+        o0, _ = ops.nlb_attnpool(xt.to(d), s_ * 256, 256, lt, s_, t_, pk)
+    finally:
+        ops.NLB_MFMA = True
+    assert_close(o1, o0, rtol=1e-4, atol_scale=1e-5)
+    ref, _ = OH.aggregate_sequences([xt[:int(lt[i]), i] for i in range(s_)], p)
+    assert_close(o1, ref)
+
+
 @pytest.mark.parametrize("qg", [(3, 5), (32, 1000), (70, 333), (256, 5000)])
 def test_pair_logits_and_topk(ops, qg):
     q, g = qg
