@@ -404,13 +404,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
             f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
             if (p.scale && nok) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
             if (p.shift && nok) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            // plain residual (the bottleneck c3 layers): a slab's residual vectors are requested BEFORE its accumulators go through
+            // the LDS transpose, so their latency runs under the 64 LDS writes instead of being waited for right behind the request
+            // (requesting the whole wave tile's vectors up front spills: the kernel sits at 247 VGPRs)
+            const bool res_plain = p.res && p.rH == 0;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        eb[((r & 3) + 8 * (r >> 2) + 4 * (lq >> 5)) * EW + j * 32 + (lq & 31)] = acc[i][j][r];
                 unsigned eo[NP];
                 f32x4 rv[NP];
 #pragma unroll
@@ -418,6 +417,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
                     const int row = wm0 + i * 32 + k * RPI + er;
                     eo[k] = nok ? (unsigned)(row * p.K + n) * 4u : kOob;
                 }
+                if (res_plain) {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, eo[k], 0, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        eb[((r & 3) + 8 * (r >> 2) + 4 * (lq >> 5)) * EW + j * 32 + (lq & 31)] = acc[i][j][r];
                 if (p.res && p.rH > 0) {
                     // nearest-upsampled residual: output pixel (img, ho, wo) reads the coarse pixel (img, ht, wt)
                     const float shs = (float)p.rH / (float)p.Ho, sws = (float)p.rW / (float)p.Wo;
@@ -431,10 +441,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
                         const unsigned uo = (nok && m < p.M) ? (unsigned)(((nl * p.rH + ht) * p.rW + wt) * p.K + n) * 4u : kOob;
                         rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uo, 0, 0));
                     }
-                } else if (p.res) {
-#pragma unroll
-                    for (int k = 0; k < NP; ++k)
-                        rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, eo[k], 0, 0));
                 }
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
