@@ -1017,6 +1017,7 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.y_f32 = y_f32;
     static const int vec_epi = getenv("SEAM_F16_VEC_EPILOGUE") ? atoi(getenv("SEAM_F16_VEC_EPILOGUE")) : 1;
     a.vec_epi = vec_epi;
+
     a.rH = rH; a.rW = rW;
     a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
     set_row_split(a);
