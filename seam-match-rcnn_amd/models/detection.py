@@ -118,7 +118,10 @@ FUSE_SHORTCUT = _os.environ.get("SEAM_FUSE_SHORTCUT", "1") != "0"
 # The stem on a space-to-depth input: 7x7 / stride 2 / pad 3 over 3 colours == 4x4 / stride 1 / pad (2 before, 1 after) over the 12
 # channels (dy, dx, c) -- the same 147 products per output in 192 reduction steps instead of 224 (SEAM_STEM_S2D=0: NHWC4 form).
 STEM_S2D = _os.environ.get("SEAM_STEM_S2D", "1") != "0"
-BODY_STREAMS = int(_os.environ.get("SEAM_BODY_STREAMS", "1"))      # ResNet body: batch slices on this many HIP streams
+# ResNet body: batch slices on this many HIP streams (bit-identical results, tested).  2 since round 2: the tail of one slice's launch
+# (3.05 rounds of tiles cost 4) runs under the other slice's next layer: 119.8 vs 121.5 ms per 8-clip step, 16.6 vs 17.0 ms at one
+# clip per step, one box (profiles/r02_body_streams.txt); 3 streams give less, 1 restores the single-stream walk.
+BODY_STREAMS = int(_os.environ.get("SEAM_BODY_STREAMS", "2"))
 
 
 class Bottleneck(nn.Module):
@@ -236,6 +239,21 @@ class ResNet50Body(nn.Module):
         return feats
 
 
+# The small pyramid levels (100^2 and below) cannot fill 256 CUs on their own; their FPN output convs and RPN-head launches run on
+# a side stream next to the 200^2 level's launches, whose blocks take the CUs they leave idle (SEAM_LEVEL_STREAMS=0: one stream).
+# Outputs are allocated on the calling stream and written through `out=`; tensors produced on one stream and read on the other are
+# registered with the caching allocator (record_stream).  Same kernels on the same data: results are bit-identical.
+LEVEL_STREAMS = _os.environ.get("SEAM_LEVEL_STREAMS", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    st = _SIDE_STREAMS.get(dev)
+    if st is None:
+        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class FeaturePyramidNetwork(nn.Module):
     def __init__(self, in_channels=(256, 512, 1024, 2048), out_channels=256):
         super().__init__()
@@ -263,13 +281,39 @@ class FeaturePyramidNetwork(nn.Module):
 
     def forward(self, feats: List[torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
         inner, layer = self.packed()
-        last = ops.conv2d(feats[3], inner[3])
-        outs = [None, None, None, ops.conv2d(last, layer[3])]
-        for i in (2, 1, 0):
-            last = ops.conv2d_topdown(feats[i], inner[i], last)      # lateral 1x1 + nearest top-down merge, one launch
-            outs[i] = ops.conv2d(last, layer[i])
+        x3 = feats[3]
+        if not (LEVEL_STREAMS and x3.is_cuda):
+            last = ops.conv2d(x3, inner[3])
+            outs = [None, None, None, ops.conv2d(last, layer[3])]
+            for i in (2, 1, 0):
+                last = ops.conv2d_topdown(feats[i], inner[i], last)      # lateral 1x1 + nearest top-down merge, one launch
+                outs[i] = ops.conv2d(last, layer[i])
+            od = OrderedDict((str(i), o) for i, o in enumerate(outs))
+            od["pool"] = ops.maxpool2d(outs[3], 1, 2, 0)          # LastLevelMaxPool
+            return od
+        # the lateral / top-down chain stays on the calling stream; the output convs of levels 3, 2, 1 (and the pool level) go to the
+        # side stream as soon as their input exists, the 200^2 output conv follows the chain on the calling stream
+        cur, side = torch.cuda.current_stream(), _side_stream(x3.device)
+        ydt = adt(self)
+        outs = [torch.empty(tuple(f.shape[:3]) + (layer[i].K,), dtype=ydt, device=x3.device) for i, f in enumerate(feats)]
+        pool = None
+        last = ops.conv2d(x3, inner[3])
+        for i in (3, 2, 1, 0):
+            if i < 3:
+                last = ops.conv2d_topdown(feats[i], inner[i], last)
+            if i == 0:
+                ops.conv2d(last, layer[0], out=outs[0])
+                break
+            side.wait_stream(cur)
+            last.record_stream(side)
+            with torch.cuda.stream(side):
+                ops.conv2d(last, layer[i], out=outs[i])
+                if i == 3:
+                    pool = ops.maxpool2d(outs[3], 1, 2, 0)      # LastLevelMaxPool
+                    pool.record_stream(cur)
+        cur.wait_stream(side)
         od = OrderedDict((str(i), o) for i, o in enumerate(outs))
-        od["pool"] = ops.maxpool2d(outs[3], 1, 2, 0)          # LastLevelMaxPool
+        od["pool"] = pool
         return od
 
 
@@ -331,7 +375,20 @@ class RPNHead(nn.Module):
     def fused(self, feats: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """-> per level the fused head output [N,H,W,A+4A] fp32 (objectness logits | deltas of each pixel)."""
         conv, heads = self.packed()
-        return [ops.conv2d(ops.conv2d(f, conv, relu=True), heads, out_f32=True) for f in feats]     # logits/deltas leave in fp32
+        feats = list(feats)
+        if not (LEVEL_STREAMS and len(feats) > 1 and feats[0].is_cuda):
+            return [ops.conv2d(ops.conv2d(f, conv, relu=True), heads, out_f32=True) for f in feats]     # logits/deltas leave in fp32
+        # level 0 on the calling stream, the smaller levels on the side stream (see LEVEL_STREAMS)
+        cur, side = torch.cuda.current_stream(), _side_stream(feats[0].device)
+        outs = [torch.empty(tuple(f.shape[:3]) + (heads.K,), dtype=torch.float32, device=f.device) for f in feats]
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for f, o in zip(feats[1:], outs[1:]):
+                f.record_stream(side)
+                ops.conv2d(ops.conv2d(f, conv, relu=True), heads, out=o, out_f32=True)
+        ops.conv2d(ops.conv2d(feats[0], conv, relu=True), heads, out=outs[0], out_f32=True)
+        cur.wait_stream(side)
+        return outs
 
 
 def _base_anchors(size: float, ratios=(0.5, 1.0, 2.0)) -> np.ndarray:

@@ -138,6 +138,37 @@ def test_body_on_two_streams_is_bit_identical(model_and_state):
         assert torch.equal(one[k], two[k]), k
 
 
+def test_level_streams_are_bit_identical(model_and_state):
+    """SEAM_LEVEL_STREAMS: the FPN output convs / RPN-head launches of the small pyramid levels on a side stream == everything on
+    one stream, bit for bit (features, RPN head outputs, proposals), in fp32 and fp16."""
+    import seam_match_rcnn_amd.models.detection as det
+    model, _ = model_and_state
+    imgs = [torch.from_numpy(synth.frames(95 + i, 1, 128, 160)[0]).to(dev()) for i in range(3)]
+    saved = model.transform.min_size, model.transform.max_size, det.LEVEL_STREAMS
+    model.transform.min_size, model.transform.max_size = 128, 160
+    try:
+        for dt in (torch.float32, torch.float16):
+            model.set_compute_dtype(dt)
+            got = {}
+            for flag in (False, True):
+                det.LEVEL_STREAMS = flag
+                with torch.no_grad():
+                    feats, sizes, orig, padded = model.extract_features(imgs)
+                    head = model.rpn.head.fused(list(feats.values()))
+                    props = model.rpn(feats, sizes, padded)
+                torch.cuda.synchronize()
+                got[flag] = (feats, head, props)
+            for k in got[False][0]:
+                assert torch.equal(got[False][0][k], got[True][0][k]), (dt, k)
+            for a, b in zip(got[False][1], got[True][1]):
+                assert torch.equal(a, b)
+            for a, b in zip(got[False][2], got[True][2]):
+                assert torch.equal(a, b)
+    finally:
+        model.set_compute_dtype(torch.float32)
+        model.transform.min_size, model.transform.max_size, det.LEVEL_STREAMS = saved
+
+
 def test_fixed_roi_forward_c1(model_and_state):
     """BASELINE config 1 shape, scaled: fixed ROIs, 16-product gallery."""
     m, sd = model_and_state
