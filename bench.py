@@ -69,6 +69,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the value_clips1 / full_forward_ms_per_clip legs")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="every launch on one HIP stream (the default runs the ResNet body on two streams and the small pyramid levels on "
+                         "a side stream: bit-identical results, ~1.4 %% faster, but concurrent kernels stretch each other's durations -- "
+                         "per-kernel profiles (rocprofv3 --stats, the PMC passes) are taken with this flag; the roofline leg always "
+                         "instruments a single-stream step)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the clip the CPU baseline times (default: all)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU runs after one warm-up; the minimum is reported")
     ap.add_argument("--graph", action="store_true",
@@ -127,6 +132,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    import seam_match_rcnn_amd.models.detection as det
+    if args.single_stream:
+        det.BODY_STREAMS, det.LEVEL_STREAMS = 1, False
     log("building synthetic weights")
     model, sd = build_model(dev)
     if args.dtype == "f16":
@@ -295,7 +303,7 @@ def main():
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": what,
-                           "clips_per_step_per_gpu": B, "hip_graph": bool(args.graph), "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
+                           "clips_per_step_per_gpu": B, "hip_graph": bool(args.graph), "hip_streams": 1 if args.single_stream else 2, "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
                            "algorithmic_tflop_per_clip": round(FLOP_PER_CLIP / 1e12, 3),
                            "parallelism": f"dp{world} (clips sharded; product bank all-gathered over RCCL)"
                            if world > 1 else "single GPU"},
@@ -321,14 +329,25 @@ def main():
 
 # ------------------------------------------------------------------------------------------------ roofline
 def roofline_leg(step, dtype):
-    """One instrumented step: every conv launch bracketed by HIP events on its launch stream (ops.CONV_TRACE)."""
+    """One instrumented step: every conv launch bracketed by HIP events on its launch stream (ops.CONV_TRACE).  The step runs on
+    ONE stream (the timed steps overlap two batch halves on two streams, which stretches every kernel's own duration: a per-kernel
+    roofline needs the kernel alone on the chip) -- the same configuration as `bench.py --single-stream`, under which the committed
+    rocprofv3 kernel stats are taken."""
     import torch
     from seam_match_rcnn_amd import ops
-    with torch.no_grad():
-        ops.CONV_TRACE = []
-        step()
-        torch.cuda.synchronize()
-        trace, ops.CONV_TRACE = ops.CONV_TRACE, None
+    import seam_match_rcnn_amd.models.detection as det
+    saved = det.BODY_STREAMS, det.LEVEL_STREAMS
+    det.BODY_STREAMS, det.LEVEL_STREAMS = 1, False
+    try:
+        with torch.no_grad():
+            step()                                  # untimed: allocator pools of the single-stream walk
+            torch.cuda.synchronize()
+            ops.CONV_TRACE = []
+            step()
+            torch.cuda.synchronize()
+            trace, ops.CONV_TRACE = ops.CONV_TRACE, None
+    finally:
+        det.BODY_STREAMS, det.LEVEL_STREAMS = saved
     per = {}
     for variant, flops, e0, e1, _shape, nbytes in trace:
         a = per.setdefault(variant, [0, 0.0, 0.0, 0.0])
@@ -359,6 +378,7 @@ def roofline_leg(step, dtype):
             "frac": round(achieved / peak, 4),
             "achieved_is": "MFMA FLOP/s issued for the algorithmic work = algorithmic_tflops x mfma_issue_ratio "
                            "(unfilled tile slots are not counted as work)",
+            "measured_on": "one instrumented step on a single stream (= bench.py --single-stream; the timed steps run two streams)",
             "algorithm": algo, "mfma_issue_ratio": round(issue, 4),
             "algorithmic_tflops": round(algorithmic, 2),
             "algorithmic_flops_are": "2*M*K*R*S*C of the direct convolution per launch (SURVEY.md 8d)",

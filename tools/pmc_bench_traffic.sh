@@ -9,7 +9,7 @@ PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "
 i=0
 for c in "${PASSES[@]}"; do
   rm -rf /tmp/pmc_$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras "$@" > /dev/null 2>/tmp/pmc_$i.err || echo "pass $c failed"
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --single-stream "$@" > /dev/null 2>/tmp/pmc_$i.err || echo "pass $c failed"
   i=$((i+1))
 done
 python3 - <<PY
@@ -44,7 +44,7 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "SQ_BUSY_CU_CYCLES" in out:
                              for k in out["SQ_VALU_MFMA_BUSY_CYCLES"] if k in out["SQ_BUSY_CU_CYCLES"]}
 import subprocess, datetime
 out["_meta"] = {"tag": "$TAG", "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
-                "command": "rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras"}
+                "command": "rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --single-stream"}
 json.dump(out, open("$R/gpurun_out/pmc_traffic_$TAG.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k in ("mfma_busy_frac",)}, indent=1))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):

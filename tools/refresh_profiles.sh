@@ -6,7 +6,7 @@ export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp
 python3 $R/bench.py > $O/${TAG}_bench.json 2>$O/${TAG}_bench.err
 rm -rf /tmp/prof_$TAG
 # kernel stats of the 8-clip steps only: --no-extras keeps the one-clip / full-forward legs (same kernels, other sizes) out of the averages
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o b -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o b -- python3 $R/bench.py --no-cpu-baseline --no-extras --single-stream > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
 cp /tmp/prof_$TAG/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null || cp /tmp/prof_$TAG/*/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
 bash $R/tools/pmc_bench_traffic.sh $TAG > $O/${TAG}_pmc.log 2>&1
 python3 $R/bench.py --workload c3 --no-roofline --cpu-runs 1 > $O/${TAG}_bench_c3.json 2>/dev/null
