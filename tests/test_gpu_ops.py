@@ -551,12 +551,12 @@ def test_rpn_topk_decode_matches_sort_and_oracle(ops):
     from seam_match_rcnn_amd.models.detection import grid_anchors
     n_img, a = 3, 3
     sizes = [(200, 304), (192, 300), (180, 250)]
-    for lvl, (h, w, k) in enumerate([(50, 76, 1000), (25, 38, 1000), (13, 19, 741), (7, 10, 97), (40, 64, 1024)]):
+    for lvl, (h, w, k) in enumerate([(50, 76, 1000), (25, 38, 1000), (13, 19, 741), (7, 10, 97), (40, 64, 1024), (1, 1, 3), (2, 3, 18), (1, 5, 1)]):
         head = rnd(950 + lvl, (n_img, h, w, 5 * a), "head")
         head[..., :a] *= 3.0
         if lvl == 1:        # heavy ties across the k-th position: quantised logits (lowest anchor index must win)
             head[..., :a] = torch.round(head[..., :a] * 2) / 2
-        if lvl == 3:
+        if lvl in (3, 6):
             head[1, ..., :a] = 0.25        # a constant row: the winners are anchors 0 .. k-1
         anc = torch.from_numpy(grid_anchors((208, 320), [(h, w)], sizes=(32 * 2 ** min(lvl, 4),))[0])
         clip = torch.tensor([[float(s[0]), float(s[1])] for s in sizes])
