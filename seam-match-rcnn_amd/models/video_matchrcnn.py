@@ -159,9 +159,25 @@ class TemporalRoIHeads(nn.Module):
         mask_proposals = [r["boxes"] for r in result]
         roi_nhwc = self.mask_roi_pool(features, mask_proposals, image_shapes)      # [K,14,14,256]
         counts = [len(p) for p in mask_proposals]
+        side = None
         if self.has_mask and self.with_masks:
-            logits = self.mask_predictor(self.mask_head(roi_nhwc))
-            probs = det.maskrcnn_inference(logits, [r["labels"] for r in result], self.num_classes)
+            # the mask branch (caller-unused, but part of the output contract) is independent of the match branch: with
+            # det.LEVEL_STREAMS it runs on the side stream next to the match trunk, whose launches fill the tails of its own
+            if det.LEVEL_STREAMS and roi_nhwc.is_cuda and roi_nhwc.shape[0] > 0:
+                cur, side = torch.cuda.current_stream(), det._side_stream(roi_nhwc.device)
+                side.wait_stream(cur)
+                roi_nhwc.record_stream(side)
+                labels = [r["labels"] for r in result]
+                for l in labels:
+                    l.record_stream(side)
+                with torch.cuda.stream(side):
+                    logits = self.mask_predictor(self.mask_head(roi_nhwc))
+                    probs = det.maskrcnn_inference(logits, labels, self.num_classes)
+                    for pr in probs:
+                        pr.record_stream(cur)
+            else:
+                logits = self.mask_predictor(self.mask_head(roi_nhwc))
+                probs = det.maskrcnn_inference(logits, [r["labels"] for r in result], self.num_classes)
             for pr, r in zip(probs, result):
                 r["masks"] = pr
         if self.has_match and roi_nhwc.shape[0] > 0:
@@ -186,6 +202,8 @@ class TemporalRoIHeads(nn.Module):
                 if self.video:
                     r['roi_features'] = roi_nchw[off:off + c]
                 off += c
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         return result
 
     def forward(self, features, proposals, image_shapes, targets=None):

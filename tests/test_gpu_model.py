@@ -156,14 +156,19 @@ def test_level_streams_are_bit_identical(model_and_state):
                     feats, sizes, orig, padded = model.extract_features(imgs)
                     head = model.rpn.head.fused(list(feats.values()))
                     props = model.rpn(feats, sizes, padded)
+                    rois = [torch.from_numpy(synth.fixed_rois(8, 128, 160)).to(dev())] * len(imgs)
+                    res, _, _ = model.forward_fixed_rois(imgs, rois)      # mask branch next to the match trunk
                 torch.cuda.synchronize()
-                got[flag] = (feats, head, props)
+                got[flag] = (feats, head, props, res)
             for k in got[False][0]:
                 assert torch.equal(got[False][0][k], got[True][0][k]), (dt, k)
             for a, b in zip(got[False][1], got[True][1]):
                 assert torch.equal(a, b)
             for a, b in zip(got[False][2], got[True][2]):
                 assert torch.equal(a, b)
+            for a, b in zip(got[False][3], got[True][3]):
+                for key in ("masks", "match_features", "roi_features"):
+                    assert torch.equal(a[key], b[key]), (dt, key)
     finally:
         model.set_compute_dtype(torch.float32)
         model.transform.min_size, model.transform.max_size, det.LEVEL_STREAMS = saved
