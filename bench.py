@@ -224,12 +224,19 @@ def main():
     value = world * B * args.steps / elapsed                                  # whole-job clips/s
 
     allgather = None
-    if world > 1 and gathers:
-        us = sorted(g.elapsed_us() for g in gathers)
-        med = us[len(us) // 2]
+    if world > 1:
+        # every rank takes part in the reduction below whether or not its own event timing worked (a rank-local failure must not
+        # leave the others waiting in a collective): -1 marks "no measurement on this rank"
+        try:
+            us = sorted(g.elapsed_us() for g in gathers)
+            med = us[len(us) // 2] if us else -1.0
+        except Exception as e:          # noqa: BLE001 -- diagnostics only, the headline number does not depend on it
+            log(f"all-gather timing unavailable: {e}")
+            med = -1.0
         tt = torch.tensor([med], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)                              # slowest rank's median
         med = float(tt.item())
+    if world > 1 and med > 0:
         shard_bytes = (retrieval.shard_range(G, 0, world)[1]) * 256 * 4       # what a rank sends to EACH peer
         allgather = {"collective": "all_gather_into_tensor (RCCL over xGMI), side stream, overlapped with the extractor",
                      "bytes_sent_per_peer": shard_bytes, "bytes_received_per_rank": (world - 1) * shard_bytes,

@@ -112,8 +112,11 @@ def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stre
                 ev[0].record()
             work = issue()
             if timed:
-                work.wait()             # stream-level wait (no host block): orders the end event behind the collective
-                ev[1].record()
+                try:
+                    work.wait()         # stream-level wait (no host block): orders the end event behind the collective
+                    ev[1].record()
+                except RuntimeError:    # a backend without stream-level waits: the gather itself is unaffected, only untimed
+                    ev = None
         return BankGather(bank, g_total, work, side_stream, sizes=sizes if ragged else None, events=ev)
     return BankGather(bank, g_total, issue(), None, sizes=sizes if ragged else None)
 
