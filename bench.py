@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the value_clips1 / full_forward_ms_per_clip legs")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="test hook: initialise the process group and issue the bank all-gather (side stream, timed) even with one rank, "
+                         "so that the N > 1 code path can be exercised on a single GPU")
     ap.add_argument("--single-stream", action="store_true",
                     help="every launch on one HIP stream (the default runs the ResNet body on two streams and the small pyramid levels on "
                          "a side stream: bit-identical results, ~1.4 %% faster, but concurrent kernels stretch each other's durations -- "
@@ -128,8 +131,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _native.lib()                                  # fail loudly if the HIP extension is missing
-    if world > 1:
+    multi = world > 1 or args.force_collective          # the data-parallel code path (collective, barriers, rank reductions)
+    out = sys.stdout
+    if multi:
+        # RCCL prints a version / host banner on the process's stdout (fd 1): keep the contract's ONE JSON line alone there by
+        # pointing fd 1 at stderr for everything else and writing the line to a duplicate of the real stdout
+        sys.stdout.flush()
+        out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:             # --force-collective outside torchrun: a one-rank group on the loopback
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     import seam_match_rcnn_amd.models.detection as det
@@ -154,11 +166,11 @@ def main():
     ids = torch.cat([c * R + torch.arange(R, dtype=torch.int64).repeat(T) for c in range(B)])   # sequence id = (clip, ROI slot)
     lo, hi = retrieval.shard_range(G, rank, world)
     bank_shard = torch.from_numpy(synth.gallery(7, G)[lo:hi]).to(dev)        # this rank's rows of the product-descriptor bank
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    side = torch.cuda.Stream(device=dev) if multi else None
     gathers = []                                                             # timed all-gathers of the measured steps
 
     def run_step(flist, rlist, ty, sid, timed_gather=False):
-        pending = retrieval.gather_product_bank(bank_shard, G, side_stream=side, timed=timed_gather)   # overlaps the extractor
+        pending = retrieval.gather_product_bank(bank_shard, G, side_stream=side, timed=timed_gather, force=multi)   # overlaps the extractor
         if timed_gather and pending.events is not None:
             gathers.append(pending)
         res, feats, rpn = model.forward_fixed_rois(flist, rlist, run_rpn_head=True)
@@ -179,7 +191,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -205,7 +217,7 @@ def main():
             log("warmup step done")
         sync_all()
         log("timing")
-        state["timed"] = world > 1 and not args.graph
+        state["timed"] = multi and not args.graph
         t0 = time.perf_counter()
         for _ in range(args.steps):
             last = run()
@@ -214,7 +226,7 @@ def main():
         state["timed"] = False
     if args.graph:
         last = graph_out
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -224,7 +236,8 @@ def main():
     value = world * B * args.steps / elapsed                                  # whole-job clips/s
 
     allgather = None
-    if world > 1:
+    med = -1.0
+    if multi:
         # every rank takes part in the reduction below whether or not its own event timing worked (a rank-local failure must not
         # leave the others waiting in a collective): -1 marks "no measurement on this rank"
         try:
@@ -236,7 +249,7 @@ def main():
         tt = torch.tensor([med], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)                              # slowest rank's median
         med = float(tt.item())
-    if world > 1 and med > 0:
+    if multi and med > 0:
         shard_bytes = (retrieval.shard_range(G, 0, world)[1]) * 256 * 4       # what a rank sends to EACH peer
         allgather = {"collective": "all_gather_into_tensor (RCCL over xGMI), side stream, overlapped with the extractor",
                      "bytes_sent_per_peer": shard_bytes, "bytes_received_per_rank": (world - 1) * shard_bytes,
@@ -326,8 +339,9 @@ def main():
             line["parity"] = parity
             if not parity["ok"]:
                 failed = f"parity outside tolerance: {parity}"
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        out.write(json.dumps(line) + "\n")
+        out.flush()
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if failed:

@@ -75,15 +75,17 @@ def _gather_into_tensor(group=None) -> bool:
     return str(dist.get_backend(group)).lower() == "nccl"
 
 
-def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stream=None, timed: bool = False) -> BankGather:
+def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stream=None, timed: bool = False,
+                        force: bool = False) -> BankGather:
     """All-gather the per-rank descriptor shards ``local[g_r,256]`` (g_r from ``shard_range``)
     into the full bank, product order preserved.  Asynchronous: returns a ``BankGather``.
 
     side_stream: optional ``torch.cuda.Stream``; the collective is enqueued there (after the
     producer of ``local`` on the current stream) so compute on the current stream overlaps it.
-    timed: bracket the collective with HIP events on the stream it runs on (``BankGather.elapsed_us``)."""
+    timed: bracket the collective with HIP events on the stream it runs on (``BankGather.elapsed_us``).
+    force: issue the collective even in a one-rank process group (exercises the N > 1 code path on a single GPU)."""
     world = _world(group)
-    if world == 1:
+    if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return BankGather(local, g_total)
     rank = dist.get_rank(group)
     sizes = [shard_range(g_total, r, world)[1] - shard_range(g_total, r, world)[0] for r in range(world)]

@@ -69,3 +69,13 @@ def test_bench_under_the_multi_gpu_launcher():
              "--workload", "c4", "--no-cpu-baseline", "--no-roofline"])
     assert d["config"]["gallery"] == 50000 and "configs[3]" in d["config"]["workload"]
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["config"]["clips_per_step_per_gpu"] == 2 and d["value"] > 1.0
+
+
+def test_data_parallel_code_path_on_one_gpu():
+    """--force-collective: RCCL process group, bank all-gather on the side stream bracketed by HIP events, barriers and the rank
+    reductions of the N > 1 path, with one rank (the driver's 8-GPU run is the first time more than one exists)."""
+    d = run([sys.executable, "bench.py", "--force-collective", "--workload", "c4", "--steps", "3", "--warmup", "1", "--clips", "1",
+             "--no-cpu-baseline", "--no-roofline", "--no-extras"])
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["config"]["gallery"] == 50000 and d["value"] > 1.0
+    a = d["allgather"]
+    assert a["median_us_slowest_rank"] > 0 and a["bytes_sent_per_peer"] == 50000 * 256 * 4 and a["bound_us_ring"] == 0.0
