@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--force-collective", action="store_true",
                     help="test hook: initialise the process group and issue the bank all-gather (side stream, timed) even with one rank, "
                          "so that the N > 1 code path can be exercised on a single GPU")
+    ap.add_argument("--stub-step", action="store_true",
+                    help="test hook (CPU, gloo): replace the GPU step by the bank all-gather alone, so that the launch / barrier / "
+                         "rank-reduction / one-line logic of the N > 1 path can run on a box without GPUs; the line says data=stub "
+                         "and is not a measurement")
     ap.add_argument("--single-stream", action="store_true",
                     help="every launch on one HIP stream (the default runs the ResNet body on two streams and the small pyramid levels on "
                          "a side stream: bit-identical results, ~1.4 %% faster, but concurrent kernels stretch each other's durations -- "
@@ -93,6 +97,70 @@ def parse():
                     help="f32 (default, the headline: exact fp32 MFMA) | f16 (config-5 style fp16 MFMA, fp32 accumulate; "
                          "extractor + trunks in fp16, descriptors / NLB / match logits fp32) | bf16x3 (split-bf16, opt-in)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_command(argv, n, port):
+    """The child command of the self-launch: N ranks of this file under torch.distributed.run on the loopback (the same
+    command line the driver uses for N > 1; the reference's own launch idiom is an external `python -m torch.distributed.launch
+    --nproc_per_node=N train_movingfashion.py ...`, ref README.md:98-110)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_self_launch(gpus, env):
+    """`python bench.py --gpus N` with N > 1 outside a launcher starts its own ranks.  SEAM_BENCH_SELF_LAUNCH=1 takes the same
+    branch with N == 1 (so that a 1-GPU box can test it)."""
+    if "WORLD_SIZE" in env or "RANK" in env:
+        return False
+    return gpus > 1 or env.get("SEAM_BENCH_SELF_LAUNCH") == "1"
+
+
+def self_launch(args, argv=None, popen=None):
+    """Start N ranks as a CHILD `python -m torch.distributed.run ... bench.py <same flags>` (subprocess, never exec; nothing in this
+    process has touched HIP yet -- torch.cuda.device_count() does not initialise the runtime), relay rank 0's single JSON line on
+    this process's stdout, everything else on stderr, and return the child's exit code.  `popen` is a test seam."""
+    import subprocess
+    argv = sys.argv[1:] if argv is None else argv
+    if popen is None:
+        import torch
+        have = args.gpus if args.stub_step else torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible on this node", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, args.gpus))))
+    env.pop("SEAM_BENCH_SELF_LAUNCH", None)
+    cmd = launch_command(argv, args.gpus, free_port())
+    log("self-launch: " + " ".join(cmd))
+    p = (popen or subprocess.Popen)(cmd, stdout=subprocess.PIPE, env=env, text=True, cwd=ROOT)
+    lines = 0
+    for raw in p.stdout:
+        s = raw.strip()
+        is_line = False
+        if s.startswith("{") and s.endswith("}"):
+            try:
+                is_line = "metric" in json.loads(s)
+            except ValueError:
+                is_line = False
+        if is_line and lines == 0:
+            lines += 1
+            sys.stdout.write(s + "\n")
+            sys.stdout.flush()
+        elif s:
+            print(s, file=sys.stderr, flush=True)
+    rc = p.wait()
+    if rc == 0 and lines != 1:
+        print("bench.py: the launched ranks printed no result line", file=sys.stderr)
+        return 1
+    return rc
 
 
 def build_model(dev):
@@ -117,6 +185,8 @@ def main():
     wl = WORKLOADS[args.workload]
     T, R, H, W, G = wl["T"], wl["R"], wl["H"], wl["W"], wl["G"]
     FLOP_PER_CLIP = flop_per_clip(wl)
+    if needs_self_launch(args.gpus, os.environ):       # before any HIP call in this process
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
     import seam_match_rcnn_amd.synth as synth
@@ -126,11 +196,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    _native.lib()                                  # fail loudly if the HIP extension is missing
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    stub = args.stub_step
+    if stub:
+        dev, dsync = torch.device("cpu"), (lambda: None)
+        args.no_roofline = args.no_cpu_baseline = args.no_extras = True
+    else:
+        torch.cuda.set_device(local_rank)
+        dev, dsync = torch.device("cuda", local_rank), torch.cuda.synchronize
+        _native.lib()                              # fail loudly if the HIP extension is missing
     multi = world > 1 or args.force_collective          # the data-parallel code path (collective, barriers, rank reductions)
     out = sys.stdout
     if multi:
@@ -142,34 +216,43 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "MASTER_ADDR" not in os.environ:             # --force-collective outside torchrun: a one-rank group on the loopback
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    import seam_match_rcnn_amd.models.detection as det
-    if args.single_stream:
-        det.BODY_STREAMS, det.LEVEL_STREAMS = 1, False
-    log("building synthetic weights")
-    model, sd = build_model(dev)
-    if args.dtype == "f16":
-        model.set_compute_dtype(torch.float16)
-    elif args.dtype == "bf16x3":      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product), fp32 accumulate
-        model.set_compute_dtype(ops.BX3)
-    log("weights on device; generating frames")
-    ta = model.roi_heads.temporal_aggregator
     B = args.clips
-    frames = torch.cat([torch.from_numpy(synth.frames(rank * B + c, T, H, W)) for c in range(B)]).to(dev)   # this rank's clips, resident
-    frame_list = list(frames.unbind(0))
-    from seam_match_rcnn_amd.models.detection import resized_size
-    rh, rw, _ = resized_size(H, W)                                           # ROIs live in the resized frame
-    rois_np = synth.fixed_rois(R, rh, rw)
-    rois = [torch.from_numpy(rois_np).to(dev) for _ in range(T * B)]
-    types = torch.zeros(B * T * R, dtype=torch.int32)                        # all street ROIs (CPU, as the ref passes)
-    ids = torch.cat([c * R + torch.arange(R, dtype=torch.int64).repeat(T) for c in range(B)])   # sequence id = (clip, ROI slot)
     lo, hi = retrieval.shard_range(G, rank, world)
     bank_shard = torch.from_numpy(synth.gallery(7, G)[lo:hi]).to(dev)        # this rank's rows of the product-descriptor bank
-    side = torch.cuda.Stream(device=dev) if multi else None
     gathers = []                                                             # timed all-gathers of the measured steps
+    model = ta = frame_list = rois = types = ids = side = None
+    if not stub:
+        import seam_match_rcnn_amd.models.detection as det
+        if args.single_stream:
+            det.BODY_STREAMS, det.LEVEL_STREAMS = 1, False
+        log("building synthetic weights")
+        model, sd = build_model(dev)
+        if args.dtype == "f16":
+            model.set_compute_dtype(torch.float16)
+        elif args.dtype == "bf16x3":      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product), fp32 accumulate
+            model.set_compute_dtype(ops.BX3)
+        log("weights on device; generating frames")
+        ta = model.roi_heads.temporal_aggregator
+        frames = torch.cat([torch.from_numpy(synth.frames(rank * B + c, T, H, W)) for c in range(B)]).to(dev)   # this rank's clips, resident
+        frame_list = list(frames.unbind(0))
+        from seam_match_rcnn_amd.models.detection import resized_size
+        rh, rw, _ = resized_size(H, W)                                           # ROIs live in the resized frame
+        rois_np = synth.fixed_rois(R, rh, rw)
+        rois = [torch.from_numpy(rois_np).to(dev) for _ in range(T * B)]
+        types = torch.zeros(B * T * R, dtype=torch.int32)                        # all street ROIs (CPU, as the ref passes)
+        ids = torch.cat([c * R + torch.arange(R, dtype=torch.int64).repeat(T) for c in range(B)])   # sequence id = (clip, ROI slot)
+        side = torch.cuda.Stream(device=dev) if multi else None
 
     def run_step(flist, rlist, ty, sid, timed_gather=False):
+        if stub:                                                                 # test hook: the exchange step alone, on CPU tensors
+            pending = retrieval.gather_product_bank(bank_shard, G, force=multi)
+            time.sleep(0.002 * (1 + rank))
+            return None, None, None, None, None, pending.wait()
         pending = retrieval.gather_product_bank(bank_shard, G, side_stream=side, timed=timed_gather, force=multi)   # overlaps the extractor
         if timed_gather and pending.events is not None:
             gathers.append(pending)
@@ -190,10 +273,10 @@ def main():
         return run_step(frame_list, rois, types, ids, timed_gather=state["timed"])
 
     def sync_all():
-        torch.cuda.synchronize()
+        dsync()
         if multi:
             dist.barrier()
-            torch.cuda.synchronize()
+            dsync()
 
     run = step
     if args.graph:
@@ -213,7 +296,7 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             run()
-            torch.cuda.synchronize()
+            dsync()
             log("warmup step done")
         sync_all()
         log("timing")
@@ -226,10 +309,22 @@ def main():
         state["timed"] = False
     if args.graph:
         last = graph_out
+    per_rank_ms = None
+    bank_agree = None
     if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_ms = [round(1e3 * float(e) / args.steps, 3) for e in every.tolist()]
+        elapsed = float(every.max().item())                                     # the contract's MAX over ranks
+        # the gathered bank must be the same [G,256] bits on every rank: min == max over ranks of a row-weighted integer checksum
+        bank = last[5]
+        wts = torch.arange(1, bank.shape[0] + 1, device=dev, dtype=torch.int64)
+        cs = (bank.contiguous().view(torch.int32).to(torch.int64).sum(1) * wts).sum().reshape(1)   # exact: order-independent integers
+        lo_cs, hi_cs = cs.clone(), cs.clone()
+        dist.all_reduce(lo_cs, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_cs, op=dist.ReduceOp.MAX)
+        bank_agree = bool(lo_cs.item() == hi_cs.item()) and tuple(bank.shape) == (G, 256)
 
     ms_per_step = 1e3 * elapsed / args.steps
     log(f"timed: {ms_per_step:.2f} ms/step")
@@ -263,8 +358,13 @@ def main():
                              "extractor's kernels, so this is an upper bound on its isolated duration"}
 
     roofline = None
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if not args.no_roofline and (multi or rank == 0):
+        # N > 1: the instrumented step contains the bank all-gather, so every rank runs it; rank 0's trace is reported
         roofline = roofline_leg(step, args.dtype)
+        if rank != 0:
+            roofline = None
+        if multi:
+            sync_all()
 
     cpu = cpu_out = None
     n_cpu = args.cpu_frames if args.cpu_frames is not None else T
@@ -321,7 +421,8 @@ def main():
         line = {"metric": metric, "value": round(value, 4),
                 "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "vs_baseline": None, "dtype": args.dtype,
+                "data": "synthetic" if not stub else "stub (--stub-step test hook: bank all-gather only, NOT a measurement)",
                 "config": {"workload": what,
                            "clips_per_step_per_gpu": B, "hip_graph": bool(args.graph), "hip_streams": 1 if args.single_stream else 2, "frames": T, "rois_per_frame": R, "gallery": G, "topk": TOPK,
                            "algorithmic_tflop_per_clip": round(FLOP_PER_CLIP / 1e12, 3),
@@ -329,6 +430,11 @@ def main():
                            if world > 1 else "single GPU"},
                 "pipeline_tflops": round(FLOP_PER_CLIP * value / 1e12, 2)}
         line.update(extras)
+        if per_rank_ms is not None:
+            line["ms_per_step_per_rank"] = per_rank_ms
+            line["bank_identical_on_all_ranks"] = bank_agree
+            if not bank_agree:
+                failed = "the all-gathered product bank differs between ranks"
         if allgather is not None:
             line["allgather"] = allgather
         if roofline is not None:

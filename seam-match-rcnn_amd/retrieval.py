@@ -68,11 +68,20 @@ class BankGather:
         return 1e3 * self.events[0].elapsed_time(self.events[1])
 
 
-def _gather_into_tensor(group=None) -> bool:
-    """Which collective form to issue -- decided ONCE from the process group's backend, so that every rank issues the
-    same call (a per-rank try/except could pair ``all_gather_into_tensor`` on one rank with ``all_gather`` on another
-    and deadlock): RCCL ("nccl") gathers into one tensor; other backends (gloo, CPU tests) use the list form."""
-    return str(dist.get_backend(group)).lower() == "nccl"
+def _gather_into_tensor(group=None, device_type: str = "cuda") -> bool:
+    """Which collective form to issue -- decided from the process group's backend CONFIGURATION and the shard's device type
+    (both rank-invariant), so that every rank issues the same call (a per-rank try/except could pair
+    ``all_gather_into_tensor`` on one rank with ``all_gather`` on another and deadlock): a CUDA shard in a group whose cuda
+    backend is RCCL ("nccl", also as part of "cpu:gloo,cuda:nccl" or a group initialised without an explicit backend) gathers
+    into one tensor; anything else (gloo, CPU tests) uses the list form."""
+    if device_type != "cuda":
+        return False
+    try:
+        cfg = str(dist.get_backend_config(group)).lower()            # e.g. "cuda:nccl" / "cpu:gloo,cuda:nccl" / "cpu:gloo"
+    except (AttributeError, RuntimeError, ValueError):
+        cfg = str(dist.get_backend(group)).lower()
+    parts = dict(p.split(":", 1) for p in cfg.split(",") if ":" in p)
+    return parts.get("cuda", cfg) == "nccl" or cfg == "nccl"
 
 
 def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stream=None, timed: bool = False,
@@ -98,7 +107,7 @@ def gather_product_bank(local: torch.Tensor, g_total: int, group=None, side_stre
         pad[:src.shape[0]] = src
         src = pad
     bank = local.new_empty((world * m, local.shape[1]))
-    into = _gather_into_tensor(group)
+    into = _gather_into_tensor(group, local.device.type)
 
     def issue():
         if into:

@@ -15,8 +15,9 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "dtype", "data", "config"}
 
 
-def run(cmd):
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+def run(cmd, **env):
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0", **env})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines                      # exactly ONE line on stdout
@@ -79,3 +80,21 @@ def test_data_parallel_code_path_on_one_gpu():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["config"]["gallery"] == 50000 and d["value"] > 1.0
     a = d["allgather"]
     assert a["median_us_slowest_rank"] > 0 and a["bytes_sent_per_peer"] == 50000 * 256 * 4 and a["bound_us_ring"] == 0.0
+
+
+def test_self_launch_branch_on_the_gpu():
+    """`python bench.py --gpus N` starts its own ranks (child torch.distributed.run, before any HIP call in the parent) and relays
+    rank 0's line; with one GPU the same branch is taken through SEAM_BENCH_SELF_LAUNCH=1.  --force-collective makes the single
+    rank run the N > 1 step (RCCL group, side-stream all-gather, rank reductions, roofline leg on the collective path)."""
+    d = run([sys.executable, "bench.py", "--gpus", "1", "--force-collective", "--workload", "c4", "--steps", "2", "--warmup", "1",
+             "--clips", "1", "--no-cpu-baseline", "--no-extras"], SEAM_BENCH_SELF_LAUNCH="1")
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["data"] == "synthetic"
+    assert d["bank_identical_on_all_ranks"] is True and len(d["ms_per_step_per_rank"]) == 1
+    assert d["allgather"]["median_us_slowest_rank"] > 0
+    assert d["roofline"]["bound"] == "mfma" and 0.3 < d["roofline"]["frac"] < 1.0        # the N > 1 line carries the roofline too
+
+
+def test_more_gpus_than_the_box_has_is_a_clean_error():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "64", "--steps", "1"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=300, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
+    assert r.returncode == 2 and "only" in r.stderr and r.stdout.strip() == ""
