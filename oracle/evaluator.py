@@ -1,15 +1,18 @@
 """ORACLE (test infrastructure, not product code) -- the evaluator's retrieval section on the CPU.
 
-A NumPy fp32 restatement of evaluate_movingfashion.py:94-334 (closures ``compute_ranking`` /
+A NumPy fp32 restatement of evaluate_movingfashion.py:26-334 (descriptor collection, closures ``compute_ranking`` /
 ``compute_distances`` / ``compute_selfdist``, the greedy tracklet builder and the seven rankings), kept in the
 reference's own loop-per-product / full-argsort form so that it checks the device implementation
 (``seam-match-rcnn_amd/evaluator.py``), which is organised differently (rank counting, batched frames).
 
-PARITY UNPINNED: ``evaluate`` cannot be imported here (module-level imports of cv2 / torchvision /
-pycocotools datasets, and the code under test is nested inside one 430-line function), so this file is
-checked only against hand-computed cases in tests/test_evaluator.py.  Deviations on purpose: fp32 tables
-instead of fp16 (:82-92); ties broken towards the lower index (NumPy's reversed unstable argsort is not
-reproducible).  Only tests/ may import this module.
+PINNED against the reference's own ``evaluate()``: tests/golden/make_eval_golden.py imports
+evaluate_movingfashion.py in the build container (stand-ins for the uninstalled modules it never calls, the real
+``TemporalAggregationNLB``), runs it over the canned-detector datasets of tests/eval_scenarios.py and stores every
+counter, the track lengths, the per-frame ranks and the descriptor tables in tests/golden/eval_golden.npz;
+tests/test_evaluator.py::test_oracle_matches_reference_evaluate asserts this file reproduces them all.
+Deviations on purpose: fp32 tables instead of fp16 (:82-92); ties broken towards the lower index (NumPy's reversed
+unstable argsort is not reproducible) -- the pinned datasets are built so that neither can change a rank, which
+``MARGIN_LOG`` measures.  Only tests/ (and the fixture generator) may import this module.
 """
 from __future__ import annotations
 
@@ -33,8 +36,62 @@ def _ranking(score_row: np.ndarray) -> np.ndarray:
     return np.argsort(-score_row, kind="stable")
 
 
-def _rank_of(score_row: np.ndarray, target: int) -> int:
+MARGIN_LOG = None      # set to a list to record (kind, relative gap between the true product's score and the nearest other score)
+
+
+def _rank_of(score_row: np.ndarray, target: int, kind: str = "rank") -> int:
+    if MARGIN_LOG is not None and score_row.size > 1:
+        s = score_row.astype(np.float64)
+        gap = np.abs(np.delete(s, target) - s[target]).min()
+        MARGIN_LOG.append((kind, float(gap / max(abs(s[target]), 1e-30))))
+        MARGIN_LOG.append(("true_score", float(s[target])))
     return int(np.flatnonzero(_ranking(score_row) == target)[0])
+
+
+def collect_tables(model, data_loader, agg_params: dict, score_threshold: float = 0.0, first_n_withvideo=None, step: int = 11) -> dict:
+    """evaluate_movingfashion.py:17-92: run `model` over the (shop picture, street frames...) batches and build the descriptor
+    tables.  `model(images)` -> list of dicts with scores / boxes / match_features / roi_features / w / b; the aggregator
+    descriptors come from ``heads.temporal_aggregation_forward`` with `agg_params` (:43-45 shop, :73-78 street)."""
+    count_products = count_street = 0
+    shop, street, aggr, gts = [], [], [], []
+    w = b = None
+    for images, targets in data_loader:
+        count_products += 1
+        output = [o for x in range(0, len(images), step) for o in model(images[x:x + step])]
+        o0 = {k: v.detach().cpu() for k, v in output[0].items()}
+        keep = o0["scores"] >= score_threshold
+        if not bool(keep.any()):
+            continue                                                              # (:34-35)
+        if w is None:
+            w, b = o0["w"].numpy(), o0["b"].numpy()
+        bs = o0["boxes"][keep]
+        maxind = int(((bs[:, 2] - bs[:, 0]) * (bs[:, 3] - bs[:, 1])).argmax())    # position among the KEPT boxes ...
+        desc = heads.temporal_aggregation_forward(o0["roi_features"][maxind][None], torch.IntTensor([1]), torch.LongTensor([0]),
+                                                  agg_params)[1]                  # ... used on the unfiltered list (:42,46), as is
+        shop.append((o0["match_features"][maxind].numpy(), count_products - 1, desc.numpy().reshape(-1),
+                     targets[0]["source"], targets[0]["i"]))
+        gts += [np.asarray(t["tracklet"], np.float32).reshape(-1)[:4] for t in targets[1:]]
+        if first_n_withvideo is not None and count_products >= first_n_withvideo:
+            continue                                                              # gallery-only product (:50-51)
+        count_street += 1
+        feats = []
+        for i, o in enumerate(output[1:]):
+            o = {k: v.detach().cpu() for k, v in o.items()}
+            for j in (o["scores"] >= score_threshold).nonzero().view(-1).tolist():
+                street.append((o["match_features"][j].numpy(), count_products - 1, i, float(o["scores"][j]), o["boxes"][j].numpy()))
+                feats.append(o["roi_features"][j][None])
+        feats = torch.cat(feats, 0)
+        n = feats.shape[0]
+        seq = heads.temporal_aggregation_forward(feats, torch.zeros(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int64),
+                                                 agg_params)[3][1:]
+        aggr.append(seq.reshape(-1, seq.shape[-1]).numpy())
+    return dict(shop_mat=np.stack([x[0] for x in shop]), shop_prods=np.asarray([x[1] for x in shop]),
+                shop_aggr=np.stack([x[2] for x in shop]), shop_sources=np.asarray([x[3] for x in shop]),
+                shop_datais=np.asarray([x[4] for x in shop]),
+                street_mat=np.stack([x[0] for x in street]), street_prods=np.asarray([x[1] for x in street]),
+                street_imgs=np.asarray([x[2] for x in street]), street_scores=np.asarray([x[3] for x in street], np.float32),
+                street_boxes=np.stack([x[4] for x in street]), street_aggr=np.concatenate(aggr),
+                tracklets_gt=np.stack(gts), w=w, b=b, count_street=count_street, count_products=count_products)
 
 
 def box_iou(a: np.ndarray, b: np.ndarray) -> np.ndarray:
@@ -65,6 +122,8 @@ def track_product(simmat, all_inds, imgs_of, scores_of, threshold):
             rows = [r for r, i in enumerate(all_inds) if i in t_inds]
             sub = simmat[rows][:, cols]
             r, c = np.unravel_index(sub.argmax(), sub.shape)
+            if MARGIN_LOG is not None:
+                MARGIN_LOG.append(("track_threshold", float(abs(sub[r, c] - threshold) / threshold)))
             if sub[r, c] > threshold:
                 t_inds.append(all_inds[cols[c]])
                 t_imgs.append(imgs_of[all_inds[cols[c]]])
@@ -118,7 +177,7 @@ def evaluate_tables(tab: dict, agg_params: dict, k_thresholds=(1, 5, 10, 20), fr
             if (track_imgs == ii).sum() > 0:
                 q = track_inds[np.flatnonzero(track_imgs == ii)]
                 row = _scores(street[q], shop, w, b)
-                r = _rank_of(row[0], shop_index)
+                r = _rank_of(row[0], shop_index, "frame")
                 best_inds.append(q[0])
                 ranks.append(r)
                 bump("frame", r, sub)
@@ -134,16 +193,16 @@ def evaluate_tables(tab: dict, agg_params: dict, k_thresholds=(1, 5, 10, 20), fr
         mask = torch.zeros((1, 1 + len(best_inds)), dtype=torch.bool)
         desc = heads.temporal_aggregation_forward(None, None, None, agg_params, x3_1_seq=seq, x3_1_mask=mask,
                                                   x3_2=torch.from_numpy(tab["shop_aggr"][shop_index:shop_index + 1]))[0][0].numpy()
-        bump("aggr_desc", _rank_of(_scores(desc[None], tab["shop_aggr"], aggr_w, aggr_b)[0], shop_index), sub)
+        bump("aggr_desc", _rank_of(_scores(desc[None], tab["shop_aggr"], aggr_w, aggr_b)[0], shop_index, "aggr_desc"), sub)
 
         # AVG DESC (:279-291)
         avg = street[best_inds].mean(0)
-        bump("avg_desc", _rank_of(_scores(avg[None], shop, w, b)[0], shop_index), sub)
+        bump("avg_desc", _rank_of(_scores(avg[None], shop, w, b)[0], shop_index, "avg_desc"), sub)
 
         # AVG & MAX DISTANCE (:293-315)
         distances = np.stack(distances)
-        bump("avg_dist", _rank_of(distances.mean(0), shop_index), sub)
-        bump("max_dist", _rank_of(distances.max(0), shop_index), sub)
+        bump("avg_dist", _rank_of(distances.mean(0), shop_index, "avg_dist"), sub)
+        bump("max_dist", _rank_of(distances.max(0), shop_index, "max_dist"), sub)
 
         # MAX CONFIDENCE SCORE (:317-328)
         pick = best_inds[int(np.asarray(scores).argmax())]

@@ -259,5 +259,8 @@ def evaluate(model, data_loader, device, score_threshold: float = 0.0, k_thresho
     """Same signature and return value (ret1, ret2, ret3) as the reference's ``evaluate``
     (evaluate_movingfashion.py:15-16,445)."""
     tables = collect_descriptors(model, data_loader, device, score_threshold, first_n_withvideo)
+    ids = getattr(getattr(data_loader, "dataset", None), "product_ids", None)
+    if ids is not None:                     # the reference keys accs_per_product by dataset.product_ids[targets[0]["i"]] (:160)
+        tables.product_keys = [ids[i] for i in tables.product_keys]
     rep = evaluate_tables(tables, model.roi_heads.temporal_aggregator, k_thresholds, frames_per_product, tracking_threshold)
     return (rep.summary(), rep) if return_report else rep.summary()

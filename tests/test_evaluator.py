@@ -9,6 +9,85 @@ from conftest import to_torch
 from oracle import evaluator as OE
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# pinned against the reference's own evaluate(): tests/golden/eval_golden.npz (made by tests/golden/make_eval_golden.py)
+REF_NAME = {"frame": "k_accs", "max_per_image": "k_accs_avg", "aggr_desc": "k_accs_aggr_desc", "avg_desc": "k_accs_avg_desc",
+            "avg_dist": "k_accs_avg_dist", "max_dist": "k_accs_max_dist", "max_score": "k_accs_max_score"}
+
+
+@pytest.fixture(scope="module")
+def eval_golden():
+    import os
+    from conftest import ROOT
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "eval_golden.npz")))
+
+
+def _check_counters(get, track_lens, frame_ranks, counts, g, name):
+    """get(table, subset) -> hit vector; counts = (count_reg, count_hard, count_street)."""
+    n = 0
+    for ours, ref in REF_NAME.items():
+        for sub in ("", "_reg", "_hard"):
+            if ours == "max_per_image" and sub:
+                continue                                   # the reference keeps no reg/hard split of "Product Max" (:243-247)
+            np.testing.assert_array_equal(get(ours, sub), g[f"{name}_{ref}{sub}"], err_msg=f"{name}: {ours}{sub}")
+            n += 1
+    assert n == 19
+    assert list(track_lens) == g[f"{name}_track_lens"].tolist()
+    assert [int(r) for r in frame_ranks] == g[f"{name}_all_ranks_list"].tolist()
+    assert tuple(int(c) for c in counts) == (int(g[f"{name}_count_reg"]), int(g[f"{name}_count_hard"]), int(g[f"{name}_count_street"]))
+
+
+@pytest.mark.parametrize("name", ["A", "B", "C"])
+def test_oracle_matches_reference_evaluate(name, eval_golden):
+    """oracle/evaluator.py (collection + tables + the seven rankings) == what the reference's own evaluate() computed on the same
+    canned-detector dataset: the 19 hit-counter vectors, count_reg / count_hard / count_street, track_lens, every per-frame rank,
+    (ret1, ret2, ret3) and the descriptor tables."""
+    import eval_scenarios as ES
+    g = eval_golden
+    loader, canned, params = ES.build(name)
+    agg_sd = to_torch(ES.aggregator_state())
+    with torch.no_grad():
+        tab = OE.collect_tables(ES.CannedModel(canned, None), loader, agg_sd, params["score_threshold"], params["first_n_withvideo"])
+    for ours, ref in (("shop_prods", "shop_prods"), ("shop_sources", "shop_sources"), ("street_prods", "street_prods"),
+                      ("street_imgs", "street_imgs")):
+        np.testing.assert_array_equal(tab[ours], g[f"{name}_tab_{ref}"])
+    np.testing.assert_array_equal(tab["street_scores"], g[f"{name}_tab_street_scores"].astype(np.float32))
+    np.testing.assert_array_equal(tab["street_boxes"], g[f"{name}_tab_street_boxes"])
+    # the reference keeps its aggregator descriptors in fp16 (:89-92): half-ulp 4.9e-4 relative
+    np.testing.assert_allclose(tab["shop_aggr"], g[f"{name}_tab_shop_aggregated_descrs"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(tab["street_aggr"], g[f"{name}_tab_street_aggr_feats"], rtol=1e-3, atol=2e-4)
+    assert tab["count_products"] == int(g[f"{name}_count_products"])
+    out = OE.evaluate_tables(tab, agg_sd, frames_per_product=params["frames_per_product"], tracking_threshold=params["tracking_threshold"])
+    _check_counters(lambda t, s: out[t + s], out["track_lens"], out["frame_ranks"],
+                    (out["count_reg"], out["count_hard"], tab["count_street"]), g, name)
+    fpp, cs = params["frames_per_product"], tab["count_street"]
+    ret = (out["frame"][0] / (cs * fpp), out["avg_desc"][0] / cs, out["aggr_desc"][0] / cs)
+    np.testing.assert_allclose(ret, g[f"{name}_ret"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["A", "B", "C"])
+def test_device_evaluate_matches_reference_evaluate(name, eval_golden):
+    """The drop-in ``evaluate(model, data_loader, device, ...)`` on the device (canned detector, device aggregator) reproduces the
+    reference's own evaluate() run: counters, track lengths, per-frame ranks, (ret1, ret2, ret3), accs_per_product."""
+    import eval_scenarios as ES
+    from seam_match_rcnn_amd import evaluator as EV
+    from seam_match_rcnn_amd.models.match_head import TemporalAggregationNLB
+    g = eval_golden
+    dev = torch.device("cuda:0")
+    loader, canned, params = ES.build(name, device=dev)
+    ta = TemporalAggregationNLB()
+    ta.load_state_dict(to_torch(ES.aggregator_state()))
+    ta = ta.to(dev).eval()
+    ret, rep = EV.evaluate(ES.CannedModel(canned, ta), loader, dev, return_report=True, **params)
+    _check_counters(lambda t, s: rep.counts[t + s], rep.track_lens, rep.frame_ranks, (rep.count_reg, rep.count_hard, rep.count_street),
+                    g, name)
+    np.testing.assert_allclose(ret, g[f"{name}_ret"], rtol=0, atol=1e-12)
+    assert [str(k) for k in rep.per_product] == g[f"{name}_per_product_keys"].tolist()
+    np.testing.assert_allclose(np.stack([v["sfmr"] for v in rep.per_product.values()]), g[f"{name}_per_product_sfmr"], atol=1e-12)
+    np.testing.assert_allclose(np.stack([v["seamrcnn"] for v in rep.per_product.values()]), g[f"{name}_per_product_seamrcnn"], atol=1e-12)
+
+
 def make_tables(seed, n_products=10, n_shop=37, frames=4, noise=0.6):
     """Synthetic descriptor tables: a true box per frame (shop descriptor + noise) and 0-2 distractor boxes."""
     rng = np.random.default_rng(seed)
