@@ -238,6 +238,9 @@ def main():
             model.set_compute_dtype(ops.BX3)
         log("weights on device; generating frames")
         ta = model.roi_heads.temporal_aggregator
+        # the step hands 'roi_features' straight to the aggregator: take the NHWC tile as a channels_last view instead of the
+        # drop-in default (a contiguous NCHW copy that the aggregator would only transpose back)
+        model.roi_heads.roi_features_contiguous = False
         frames = torch.cat([torch.from_numpy(synth.frames(rank * B + c, T, H, W)) for c in range(B)]).to(dev)   # this rank's clips, resident
         frame_list = list(frames.unbind(0))
         from seam_match_rcnn_amd.models.detection import resized_size

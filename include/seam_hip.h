@@ -446,6 +446,16 @@ int seam_nlb_attnpool_bwd_f32(const float* seq, int64_t t_stride, int64_t s_stri
                               const float* b_att, const float* dout, float* dseq, float* const* grads,
                               float* ws, int use_nlb, seam_stream_t stream);
 
+/* Gradients of the non-local block ALONE -- the z output of seam_nlb_attnpool_f32, i.e. NONLocalBlock1D.forward called
+ * directly and grad-enabled (ref models/nlb.py:66-101): dz rows at dz + s*dz_s_stride + t*dz_t_stride (256 floats each)
+ * -> dseq (as above) and grads[9] = the first nine pointers of the list above (no attention scorer behind a direct call).
+ * Same workspace as seam_nlb_attnpool_bwd_f32. */
+int seam_nlb_block_bwd_f32(const float* seq, int64_t t_stride, int64_t s_stride, const int* len, int S, int Tmax,
+                           const float* w_proj_t, const float* b_proj, const float* w_cat,
+                           const float* w_out_t, const float* b_out, const float* dz, int64_t dz_t_stride,
+                           int64_t dz_s_stride, float* dseq, float* const* grads, float* ws, int use_nlb,
+                           seam_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Input pipeline on the device: what MovingFashionDataset.__getitem__ does to a decoded
  * frame (datasets/MFDataset.py:79-93), on uint8 [H,W,3] device images.

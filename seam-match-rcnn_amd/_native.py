@@ -110,6 +110,7 @@ SIGNATURES = {
     "seam_pair_logits_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "seam_nlb_bwd_workspace_floats": (_i64, [_i, _i]),
     "seam_nlb_attnpool_bwd_f32": (_i, [_p, _i64, _i64, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), _p, _i, _p]),
+    "seam_nlb_block_bwd_f32": (_i, [_p, _i64, _i64, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, C.POINTER(_p), _p, _i, _p]),
 }
 
 _lib = None

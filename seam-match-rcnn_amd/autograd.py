@@ -107,6 +107,36 @@ class NlbAttnPoolFunction(torch.autograd.Function):
         return (dseq, None, None, *grads)
 
 
+class NlbBlockFunction(torch.autograd.Function):
+    """The non-local block alone, ``NONLocalBlock1D.forward`` called directly (ref models/nlb.py:66-101):
+    x [b,256,t] -> z [b,256,t].  The block is applied whatever t is (the length-1 bypass is the aggregator's rule)."""
+
+    @staticmethod
+    def forward(ctx, x, theta_w, theta_b, phi_w, phi_b, g_w, g_b, cat_w, W_w, W_b):
+        b, c, t = x.shape
+        xt = ops.nchw_to_nhwc(x.detach().to(F32).contiguous().view(b, c, t))             # rows [b,t,256]
+        dev = x.device
+        pk = ops.PackedNLB(
+            w_proj_t=torch.cat([theta_w[:, :, 0], phi_w[:, :, 0], g_w[:, :, 0]], 0).detach().t().contiguous(),
+            b_proj=torch.cat([theta_b, phi_b, g_b]).detach().contiguous(),
+            w_cat=cat_w.detach().reshape(256).contiguous(),
+            w_out_t=W_w.detach()[:, :, 0].t().contiguous(), b_out=W_b.detach().contiguous(),
+            w_att=torch.zeros(256, device=dev), b_att=torch.zeros(1, device=dev))
+        lens = torch.full((b,), t, dtype=torch.int32, device=dev)
+        _, _, z = ops.nlb_attnpool(xt, 256, t * 256, lens, b, t, pk, use_nlb=2, want_z=True)
+        ctx.save_for_backward(xt, lens)
+        ctx.pk = pk
+        return ops.nhwc_to_nchw(z)
+
+    @staticmethod
+    def backward(ctx, dz):
+        xt, lens = ctx.saved_tensors
+        b, t, _ = xt.shape
+        dzt = ops.nchw_to_nhwc(dz.contiguous().to(F32))                                    # [b,t,256]
+        dxt, grads = ops.nlb_block_bwd(xt, 256, t * 256, lens, b, t, ctx.pk, dzt, 256, t * 256, use_nlb=2)
+        return (ops.nhwc_to_nchw(dxt), *grads)
+
+
 class WeightedCE2Function(torch.autograd.Function):
     """nn.CrossEntropyLoss(weight=[w0,w1]) over [n,2] logits (the criterion of every loss in the reference's
     models/match_head.py:213,257,367,386): weighted mean of -log softmax(x)[y]."""

@@ -314,6 +314,8 @@ struct NlbBwdArgs {
     const float* w_att;        // [256]
     const float* b_att;        // [1]
     const float* dout;         // [S][256]
+    const float* dz_ext;       // optional [row = s*dz_s_stride + t*dz_t_stride][256]: the gradient w.r.t. the block's OUTPUT rows z
+    int64_t dz_t_stride, dz_s_stride;   //   (direct callers of NONLocalBlock1D.forward); replaces the pooling backward, dout unused
     float* dseq;               // same strides as seq
     // per-row scratch, row id = s*Tmax + t
     float* G;                  // [rows][128]
@@ -334,14 +336,15 @@ __global__ __launch_bounds__(256) void nlb_bwd_seq_kernel(const NlbBwdArgs p) {
     __shared__ float av[TB], bv[TB], ev[TB], sv[TB], dav[TB], dbv[TB];
     __shared__ float dS[TB][TB + 1];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int T = p.len[s];
+    const int T = min(p.len[s], p.Tmax);              // a length beyond the packed rows would index LDS / scratch out of range
     if (T <= 0) return;
     const float* X = p.seq + (int64_t)s * p.s_stride;
     float* dX = p.dseq + (int64_t)s * p.s_stride;
     const size_t r0 = (size_t)s * p.Tmax;
     const bool nlb = p.use_nlb == 2 || (p.use_nlb && T > 1);
     const float Tf = (float)T;
-    const float wa = p.w_att[tid], ba = p.b_att[0];
+    const bool pooled = p.dz_ext == nullptr;
+    const float wa = pooled ? p.w_att[tid] : 0.f, ba = pooled ? p.b_att[0] : 0.f;
 
     if (nlb) {
         const float wc = p.w_cat[tid], bp0 = p.b_proj[tid], bp1 = tid < DI ? p.b_proj[256 + tid] : 0.f;
@@ -388,28 +391,33 @@ __global__ __launch_bounds__(256) void nlb_bwd_seq_kernel(const NlbBwdArgs p) {
     }
     __syncthreads();
     // softmax over t; ds_t = dout . Z_t ; de = s (ds - sum s ds)
-    const float dov = p.dout[(size_t)s * D + tid];
-    float m = -INFINITY;
-    for (int t = 0; t < T; ++t) m = fmaxf(m, ev[t]);
-    float l = 0.f;
-    for (int t = 0; t < T; ++t) l += expf(ev[t] - m);
-    for (int t = 0; t < T; ++t) {
-        const float ds = block_sum(dov * p.Z[(r0 + t) * D + tid], red);
-        if (tid == 0) { sv[t] = expf(ev[t] - m) / l; dav[t] = ds; }      // dav: temporary home of ds
+    const float dov = pooled ? p.dout[(size_t)s * D + tid] : 0.f;
+    if (pooled) {
+        float m = -INFINITY;
+        for (int t = 0; t < T; ++t) m = fmaxf(m, ev[t]);
+        float l = 0.f;
+        for (int t = 0; t < T; ++t) l += expf(ev[t] - m);
+        for (int t = 0; t < T; ++t) {
+            const float ds = block_sum(dov * p.Z[(r0 + t) * D + tid], red);
+            if (tid == 0) { sv[t] = expf(ev[t] - m) / l; dav[t] = ds; }  // dav: temporary home of ds
+        }
+        __syncthreads();
+        float dot = 0.f;
+        for (int t = 0; t < T; ++t) dot = fmaf(sv[t], dav[t], dot);
+        __syncthreads();
+        if (tid < T) {
+            const float de = sv[tid] * (dav[tid] - dot);
+            dbv[tid] = de;                                               // dbv: temporary home of de
+            p.vec[(r0 + tid) * 3 + 2] = de;
+        }
+    } else if (tid < T) {
+        p.vec[(r0 + tid) * 3 + 2] = 0.f;                                 // no attention scorer behind a direct block call
     }
     __syncthreads();
-    float dot = 0.f;
-    for (int t = 0; t < T; ++t) dot = fmaf(sv[t], dav[t], dot);
-    __syncthreads();
-    if (tid < T) {
-        const float de = sv[tid] * (dav[tid] - dot);
-        dbv[tid] = de;                                                   // dbv: temporary home of de
-        p.vec[(r0 + tid) * 3 + 2] = de;
-    }
-    __syncthreads();
-    // dZ_t = s_t dout + de_t wa
+    // dZ_t = s_t dout + de_t wa   (or handed in by the caller)
     for (int t = 0; t < T; ++t) {
-        const float dz = fmaf(sv[t], dov, dbv[t] * wa);
+        const float dz = pooled ? fmaf(sv[t], dov, dbv[t] * wa)
+                                : p.dz_ext[(int64_t)s * p.dz_s_stride + (int64_t)t * p.dz_t_stride + tid];
         dX[(int64_t)t * p.t_stride + tid] = dz;                          // residual path (the whole gradient when bypassed)
         p.dZn[(r0 + t) * D + tid] = nlb ? dz : 0.f;
     }
@@ -679,8 +687,14 @@ int seam_pair_logits_bwd_f32(const float* a, const float* b, const float* w, con
 }
 
 int64_t seam_nlb_bwd_workspace_floats(int S, int Tmax) {
-    return (int64_t)S * Tmax * (DI * 4 + D * 2 + 3) + 2 * D + 2 + 16;
+    return (int64_t)S * Tmax * (DI * 4 + D * 2 + 3) + 2 * D + 2 + 16 + D + 16;
 }
+
+static int nlb_bwd_launch(const float* seq, int64_t t_stride, int64_t s_stride, const int* len, int S, int Tmax,
+                          const float* w_proj_t, const float* b_proj, const float* w_cat, const float* w_out_t,
+                          const float* b_out, const float* w_att, const float* b_att, const float* dout,
+                          const float* dz, int64_t dz_t_stride, int64_t dz_s_stride,
+                          float* dseq, float* const* grads, int n_grads, float* ws, int use_nlb, void* stream);
 
 // Gradients of seam_nlb_attnpool_f32 (same operand layouts).  grads: 11 output pointers in the reference's parameter
 // layouts: theta.weight [128,256], theta.bias [128], phi.weight, phi.bias, g.weight, g.bias, concat_project [256],
@@ -689,6 +703,26 @@ int seam_nlb_attnpool_bwd_f32(const float* seq, int64_t t_stride, int64_t s_stri
                               const float* w_proj_t, const float* b_proj, const float* w_cat, const float* w_out_t,
                               const float* b_out, const float* w_att, const float* b_att, const float* dout,
                               float* dseq, float* const* grads, float* ws, int use_nlb, void* stream) {
+    return nlb_bwd_launch(seq, t_stride, s_stride, len, S, Tmax, w_proj_t, b_proj, w_cat, w_out_t, b_out, w_att, b_att, dout,
+                          nullptr, 0, 0, dseq, grads, 11, ws, use_nlb, stream);
+}
+
+// Gradients of the non-local block ALONE (seam_nlb_attnpool_f32's z output; ref models/nlb.py:66-101 called directly):
+// dz rows [s*dz_s_stride + t*dz_t_stride][256] -> dseq and grads[9] (the first nine of the list above).
+int seam_nlb_block_bwd_f32(const float* seq, int64_t t_stride, int64_t s_stride, const int* len, int S, int Tmax,
+                           const float* w_proj_t, const float* b_proj, const float* w_cat, const float* w_out_t,
+                           const float* b_out, const float* dz, int64_t dz_t_stride, int64_t dz_s_stride,
+                           float* dseq, float* const* grads, float* ws, int use_nlb, void* stream) {
+    if (dz == nullptr) return (int)hipErrorInvalidValue;
+    return nlb_bwd_launch(seq, t_stride, s_stride, len, S, Tmax, w_proj_t, b_proj, w_cat, w_out_t, b_out, nullptr, nullptr, nullptr,
+                          dz, dz_t_stride, dz_s_stride, dseq, grads, 9, ws, use_nlb, stream);
+}
+
+static int nlb_bwd_launch(const float* seq, int64_t t_stride, int64_t s_stride, const int* len, int S, int Tmax,
+                          const float* w_proj_t, const float* b_proj, const float* w_cat, const float* w_out_t,
+                          const float* b_out, const float* w_att, const float* b_att, const float* dout,
+                          const float* dz, int64_t dz_t_stride, int64_t dz_s_stride,
+                          float* dseq, float* const* grads, int n_grads, float* ws, int use_nlb, void* stream) {
     if (S <= 0) return 0;
     if (Tmax > TB || Tmax <= 0) return (int)hipErrorInvalidValue;
     NlbParamArgs pa;
@@ -696,6 +730,7 @@ int seam_nlb_attnpool_bwd_f32(const float* seq, int64_t t_stride, int64_t s_stri
     a.seq = seq; a.t_stride = t_stride; a.s_stride = s_stride; a.len = len; a.S = S; a.Tmax = Tmax;
     a.w_proj_t = w_proj_t; a.b_proj = b_proj; a.w_cat = w_cat; a.w_out_t = w_out_t; a.b_out = b_out;
     a.w_att = w_att; a.b_att = b_att; a.dout = dout; a.dseq = dseq; a.use_nlb = use_nlb;
+    a.dz_ext = dz; a.dz_t_stride = dz_t_stride; a.dz_s_stride = dz_s_stride;
     const size_t rows = (size_t)S * Tmax;
     float* q = ws;
     a.G = q; q += rows * DI;
@@ -705,10 +740,11 @@ int seam_nlb_attnpool_bwd_f32(const float* seq, int64_t t_stride, int64_t s_stri
     a.Z = q; q += rows * D;
     a.dZn = q; q += rows * D;
     a.vec = q; q += rows * 3;
-    pa.tmp = q;
+    pa.tmp = q; q += 2 * D + 2 + 16;
     pa.d_theta_w = grads[0]; pa.d_theta_b = grads[1]; pa.d_phi_w = grads[2]; pa.d_phi_b = grads[3];
     pa.d_g_w = grads[4]; pa.d_g_b = grads[5]; pa.d_cat = grads[6]; pa.d_W_w = grads[7]; pa.d_W_b = grads[8];
-    pa.d_att_w = grads[9]; pa.d_att_b = grads[10];
+    if (n_grads >= 11) { pa.d_att_w = grads[9]; pa.d_att_b = grads[10]; }
+    else { pa.d_att_w = q; pa.d_att_b = q + D; }          // no scorer behind a direct block call: zeros land in scratch
     hipLaunchKernelGGL(nlb_bwd_seq_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(nlb_param_grad_kernel, dim3(DI + D + 1), dim3(256), 0, (hipStream_t)stream, pa);
     hipLaunchKernelGGL(nlb_param_assemble_kernel, dim3(2 * DI), dim3(256), 0, (hipStream_t)stream, pa);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void nlb_attnpool_kernel(const NlbArgs p) {
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int T = p.len[s];
+    const int T = min(p.len[s], p.Tmax);              // a length beyond the packed rows would index LDS / scratch out of range
     const float* X = p.seq + (int64_t)s * p.s_stride;
     float* outp = p.out + (size_t)s * D;
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void nlb_attnpool_mfma_kernel(const NlbMfArgs 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int nl = lane & 31, h = lane >> 5;
-    const int T = p.len[s];
+    const int T = min(p.len[s], p.Tmax);              // a length beyond the packed rows would index LDS / scratch out of range
     const float* X = p.seq + (int64_t)s * p.s_stride;
     float* outp = p.out + (size_t)s * D;
     if (T <= 0) { outp[tid] = 0.f; return; }

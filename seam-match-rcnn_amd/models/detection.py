@@ -195,7 +195,8 @@ class ResNet50Body(nn.Module):
             # slice sits in an HBM-bound layer (the 1x1 expansions with their residual) another one runs an MFMA-bound layer on
             # the same CUs.  Per-image results do not depend on the batch an image rides in (tested), so this is the same math.
             cur = torch.cuda.current_stream()
-            if getattr(self, "_streams", None) is None or len(self._streams) != BODY_STREAMS:
+            if (getattr(self, "_streams", None) is None or len(self._streams) != BODY_STREAMS
+                    or self._streams[0].device != x.device):            # rebuilt after model.to(another device)
                 self._streams = [torch.cuda.Stream(device=x.device) for _ in range(BODY_STREAMS)]
             h1, w1 = ((x.shape[1], x.shape[2]) if x.shape[-1] == 12 else
                       ((x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1))

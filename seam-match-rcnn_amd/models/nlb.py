@@ -71,8 +71,11 @@ class _NonLocalBlockND(nn.Module):
 
     def forward(self, x):
         """x: (b, 256, t) -> z: (b, 256, t)      (ref models/nlb.py:66-101)"""
-        if torch.is_grad_enabled() and (x.requires_grad or self.W.weight.requires_grad and self.training):
-            raise NotImplementedError("backward of the non-local block is not built (SURVEY.md 8f row f2)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # grad-enabled direct call: the same forward kernel with the block's own backward behind it (t <= 64)
+            from ..autograd import NlbBlockFunction
+            return NlbBlockFunction.apply(x, self.theta.weight, self.theta.bias, self.phi.weight, self.phi.bias, self.g.weight,
+                                          self.g.bias, self.concat_project[0].weight, self.W.weight, self.W.bias)
         b, c, t = x.shape
         xt = ops.nchw_to_nhwc(x.detach().contiguous().view(b, c, t))            # [b,t,256]
         lens = torch.full((b,), t, dtype=torch.int32, device=x.device)

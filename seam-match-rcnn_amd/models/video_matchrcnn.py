@@ -36,7 +36,9 @@ class TemporalRoIHeads(nn.Module):
     library's NHWC FPN maps; everything else keeps the reference's meaning."""
 
     video = True                    # emit 'roi_features' (ref :314); NewRoIHeads does not
-    roi_features_contiguous = False  # True: 'roi_features' as a contiguous NCHW copy instead of a channels_last view
+    roi_features_contiguous = True   # 'roi_features' is a fresh contiguous NCHW tensor, as the reference returns (ref :314);
+    #                                  False: an NCHW-shaped channels_last VIEW of the RoIAlign tile (no transpose pass; opt-in for
+    #                                  pipelines whose only consumer is the aggregator, e.g. bench.py)
     nms_prefix = 4096                # candidates per image that enter the detection NMS (exactness is checked, see postprocess_detections)
     fallback_score = 0.1            # ref :252 (1.0 in models/matchrcnn.py:377)
 
@@ -58,6 +60,8 @@ class TemporalRoIHeads(nn.Module):
         self.detections_per_img = box_detections_per_img
         self.num_classes = num_classes
         self.with_masks = True      # set False to skip the (caller-unused) mask branch
+        if not 0 < int(self.nms_prefix) <= det.NMS_MAX_BOXES:
+            raise ValueError(f"nms_prefix must be in 1..{det.NMS_MAX_BOXES}, got {self.nms_prefix}")
 
     has_mask = property(lambda self: self.mask_roi_pool is not None and self.mask_head is not None
                         and self.mask_predictor is not None)
@@ -98,11 +102,14 @@ class TemporalRoIHeads(nn.Module):
         # candidates would cost a 21 MB bit matrix per image for 100 detections).  Exact whenever the prefix holds
         # detections_per_img survivors or all valid candidates -- checked on the device and read back with the counts (the one
         # sync); otherwise the call is repeated on everything, or per image when that exceeds the kernel's capacity.
-        prefix = self.nms_prefix if c > self.nms_prefix else 0
+        # (a prefix outside 1..NMS_MAX_BOXES -- the attribute was changed after construction -- is clamped: whenever c exceeds
+        # the kernel's per-image capacity SOME prefix must be used, and the exactness check below catches the rest)
+        big = c > det.NMS_MAX_BOXES
+        prefix = min(max(int(self.nms_prefix), 1), det.NMS_MAX_BOXES) if (c > self.nms_prefix or big) else 0
         order, sel, exact = det.batched_nms_images(pb, ps, labels, valid, self.nms_thresh, self.detections_per_img, prefix)
         stats = torch.cat([sel.sum(1), exact.to(torch.int64)]).tolist()                      # one sync
         if not all(stats[n_img:]):
-            if c > det.NMS_MAX_BOXES:       # beyond the batched NMS kernel's per-image capacity (e.g. 91 classes): per-image path
+            if big:                         # beyond the batched NMS kernel's per-image capacity (e.g. 91 classes): per-image path
                 return self._postprocess_per_image(boxes.view(-1, num_classes, 4), pred_scores, counts)
             order, sel, _ = det.batched_nms_images(pb, ps, labels, valid, self.nms_thresh, self.detections_per_img)
             stats = sel.sum(1).tolist()
@@ -184,10 +191,10 @@ class TemporalRoIHeads(nn.Module):
             # types = 0 for image 0's ROIs, 1 for all others (ref :299-307); the pairwise logits the
             # reference computes here are dropped by every caller (ref :309), only x3 is kept
             final_features = self.match_predictor.trunk_nhwc(roi_nhwc)
-            # 'roi_features' [K,256,14,14] (ref :314).  Exact-fp32 path: an NCHW-shaped VIEW of the NHWC tile RoIAlign wrote
-            # (torch's channels_last memory format: same shape, same values, no transpose pass) -- the aggregator, its only
-            # consumer (stuffs/engine.py:158, evaluate_movingfashion.py:42), reads that layout back without a copy.
-            # ``roi_features_contiguous = True`` restores a contiguous NCHW copy; the fp16 path always converts (fp32 output).
+            # 'roi_features' [K,256,14,14] (ref :314): a contiguous NCHW copy by default (one transpose kernel).  With
+            # ``roi_features_contiguous = False`` the exact-fp32 path hands out an NCHW-shaped VIEW of the NHWC tile RoIAlign wrote
+            # (torch's channels_last memory format: same shape and values, no transpose pass) -- the aggregator reads that layout
+            # back without a copy; the fp16 path always converts (fp32 output).
             roi_nchw = None
             if self.video:
                 if roi_nhwc.dtype == torch.float32 and not self.roi_features_contiguous:

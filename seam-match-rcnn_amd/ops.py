@@ -324,6 +324,25 @@ def nlb_attnpool_bwd(seq, t_stride, s_stride, lens, n_seq, t_max, pk: "PackedNLB
     return dseq, grads
 
 
+def nlb_block_bwd(seq, t_stride, s_stride, lens, n_seq, t_max, pk: "PackedNLB", dz, dz_t_stride, dz_s_stride, use_nlb=2):
+    """Gradients of the non-local block alone (the ``z`` output of ``nlb_attnpool``): dz rows -> (dseq like seq, [9 parameter
+    gradients: theta.w, theta.b, phi.w, phi.b, g.w, g.b, concat_project.w, W.w, W.b])."""
+    lib = _native.lib()
+    seq, dz = _req(seq, name="seq"), _req(dz, name="dz")
+    dev = seq.device
+    dseq = torch.zeros_like(seq)
+    shapes = [(128, 256, 1), (128,), (128, 256, 1), (128,), (128, 256, 1), (128,), (1, 256, 1, 1), (256, 128, 1), (256,)]
+    grads = [torch.zeros(sh, dtype=F32, device=dev) for sh in shapes]
+    if n_seq:
+        ws = torch.empty((int(lib.seam_nlb_bwd_workspace_floats(n_seq, t_max)),), dtype=F32, device=dev)
+        arr = (C.c_void_p * 9)(*[g.data_ptr() for g in grads])
+        _native.check(lib.seam_nlb_block_bwd_f32(_ptr(seq), t_stride, s_stride, _ptr(_req(lens, torch.int32, "lens")), n_seq, t_max,
+                                                 _ptr(pk.w_proj_t), _ptr(pk.b_proj), _ptr(pk.w_cat), _ptr(pk.w_out_t), _ptr(pk.b_out),
+                                                 _ptr(dz), dz_t_stride, dz_s_stride, _ptr(dseq), arr, _ptr(ws), int(use_nlb), _stream()),
+                      "seam_nlb_block_bwd_f32")
+    return dseq, grads
+
+
 def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_f32: bool = False, out_hw: Optional[tuple] = None) -> torch.Tensor:
     """NHWC implicit-GEMM conv (+scale/shift, +residual, +ReLU) -> NHWC [N,Ho,Wo,K].

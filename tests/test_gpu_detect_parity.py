@@ -1,7 +1,8 @@
 """Model-level parity of the DISCRETE stages (RPN proposal selection, box-head post-processing, the image model of row a15)
-against the oracle, compared as IoU-matched sets: every oracle box must have a partner on the device with (nearly) the same
-coordinates, the same label and the same score, and vice versa.  Top-k / NMS decisions on values that differ by 1e-6 between
-two fp32 implementations can flip for a handful of near-ties, so the bar is a matched fraction, not element order."""
+against the oracle, compared as EXACT sets: every oracle box must have a partner on the device with the same label, coordinates
+within 0.05 px and the same score, and vice versa.  Top-k / NMS decisions on values that differ by 1e-6 between two fp32
+implementations can flip for a handful of near-ties: those are counted, printed and bounded (tests/parity_sets.py); the
+full-size (800x800) variant is tests/test_gpu_forward_fullsize.py."""
 import pytest
 import torch
 
@@ -10,6 +11,7 @@ from conftest import to_torch
 from oracle import detection as OD
 from oracle import heads as OH
 from oracle import model as OM
+from parity_sets import assert_same_set
 from test_gpu_ops import assert_close
 
 pytestmark = pytest.mark.gpu
@@ -58,13 +60,11 @@ def test_rpn_proposals_match_oracle(model_and_state):
         props = m.rpn(feats, sizes, padded)
     ofe, osz, opad = OM.extract_features(imgs, sd, 256, 320)
     oprops, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
-    for p, o in zip(props, oprops):
-        assert abs(len(p) - len(o)) <= max(3, len(o) // 100), (len(p), len(o))
-        fa, fb, _ = match_sets(o, p, thr=0.98)
-        assert fa >= 0.98 and fb >= 0.98, (fa, fb)
-        # proposals come out in descending objectness order: the leading ones agree position by position
-        lead = min(len(p), len(o)) // 4
-        assert float((iou_matrix(o[:lead], p[:lead]).diagonal() >= 0.98).float().mean()) >= 0.9
+    for i, (p, o) in enumerate(zip(props, oprops)):
+        partner = assert_same_set(o, p, tol_px=1e-2, max_flips=5, what=f"RPN proposals 256x320 image {i}")
+        # proposals come out in descending objectness order: position by position, flips aside
+        ok = partner >= 0
+        assert int((partner[ok] == torch.arange(len(o))[ok]).sum()) >= int(ok.sum()) - 10
 
 
 def test_full_forward_detections_match_oracle(model_and_state):
@@ -77,13 +77,11 @@ def test_full_forward_detections_match_oracle(model_and_state):
     ofe, osz, opad = OM.extract_features(imgs, sd, 256, 320)
     oprops, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
     ref = OM.detect(ofe, oprops, osz, sd, 0.1)
-    for o, r in zip(out, ref):
-        assert abs(len(o["scores"]) - len(r["scores"])) <= 2
-        fa, fb, partner = match_sets(r["boxes"], o["boxes"], r["labels"], o["labels"], thr=0.98)
-        assert fa >= 0.9 and fb >= 0.9, (fa, fb)
+    for i, (o, r) in enumerate(zip(out, ref)):
+        partner = assert_same_set(r["boxes"], o["boxes"], r["labels"], o["labels"], r["scores"], o["scores"], max_flips=5,
+                                  what=f"detections 256x320 image {i}")
         ok = partner >= 0
-        assert_close(o["scores"].cpu()[partner[ok]], r["scores"][ok], rtol=2e-3)
-        assert_close(o["boxes"].cpu()[partner[ok]], r["boxes"][ok], rtol=2e-3, atol_scale=1e-3)
+        assert_close(o["scores"].cpu()[partner[ok]], r["scores"][ok], rtol=1e-4)
         assert torch.equal(o["labels"].cpu()[partner[ok]], r["labels"][ok])
 
 
@@ -116,10 +114,10 @@ def test_image_model_forward_vs_oracle_with_real_detections(model_and_state):
         assert set(o) == {"boxes", "labels", "scores", "masks", "match_features", "w", "b"}       # no roi_features (ref :465-468)
         assert torch.equal(o["w"].cpu(), mp["last.weight"]) and torch.equal(o["b"].cpu(), mp["last.bias"])
         assert o["match_features"].shape == (len(o["scores"]), 256) and o["masks"].shape[1:] == (1, 192, 256)
-        fa, fb, partner = match_sets(r["boxes"], o["boxes"], r["labels"], o["labels"], thr=0.98)   # identity scale: same pixels
-        assert fa >= 0.9 and fb >= 0.9, (fa, fb)
+        partner = assert_same_set(r["boxes"], o["boxes"], r["labels"], o["labels"], r["scores"], o["scores"], max_flips=5,
+                                  what="image-model detections 192x256")               # identity scale: same pixels
         ok = partner >= 0
-        assert_close(o["scores"].cpu()[partner[ok]], r["scores"][ok], rtol=2e-3)
+        assert_close(o["scores"].cpu()[partner[ok]], r["scores"][ok], rtol=1e-4)
         # descriptors of matched detections: boxes agree to ~1e-4 px, so RoIAlign + trunk agree to the usual tolerance
         assert_close(o["match_features"].cpu()[partner[ok]], ox3[off:off + c][ok], rtol=5e-3, atol_scale=2e-3)
         pasted = OD.paste_masks_in_image(pr, r["boxes"], (192, 256))
@@ -149,3 +147,39 @@ def test_model_refuses_cpu_images(model_and_state):
                 m(list(clip.unbind(0)))                    # NHWC8 batch branch
         finally:
             m.set_compute_dtype(torch.float32)
+
+
+def test_91_classes_and_out_of_range_prefix():
+    """COCO-sized head: 90 foreground classes x up to 1000 proposals = up to 90 000 class candidates per image, far beyond the NMS
+    kernel's 16 384-box capacity: the prefix is what keeps the call legal, so a prefix changed to 0 or past the capacity after
+    construction is clamped instead of reaching the kernel (which would answer hipErrorInvalidValue)."""
+    from seam_match_rcnn_amd.models.video_matchrcnn import videomatchrcnn_resnet50_fpn, TemporalRoIHeads
+    sd = to_torch(synth.video_matchrcnn_state(5, 91))
+    m = videomatchrcnn_resnet50_fpn(pretrained_backbone=False, num_classes=91)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.transform.min_size, m.transform.max_size = 256, 320
+    imgs = [torch.from_numpy(synth.frames(160 + i, 1, 256, 320)[0]).to(DEV) for i in range(2)]
+    with torch.no_grad():
+        base = m(imgs)
+        outs = []
+        for prefix in (0, 50000, 16384, 100):
+            m.roi_heads.nms_prefix = prefix
+            outs.append(m(imgs))
+    for out in outs:
+        for o, b in zip(out, base):
+            assert torch.equal(o["boxes"], b["boxes"]) and torch.equal(o["labels"], b["labels"]) and torch.equal(o["scores"], b["scores"])
+    # vs the oracle's per-class NMS over ALL candidates
+    cpu = [i.cpu() for i in imgs]
+    ofe, osz, opad = OM.extract_features(cpu, sd, 256, 320)
+    oprops, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
+    ref = OM.detect(ofe, oprops, osz, sd, 0.1)
+    for i, (o, r) in enumerate(zip(base, ref)):
+        assert_same_set(r["boxes"], o["boxes"], r["labels"], o["labels"], r["scores"], o["scores"], max_flips=5,
+                        what=f"91-class detections image {i}")
+    try:
+        TemporalRoIHeads.nms_prefix = 0
+        with pytest.raises(ValueError):
+            TemporalRoIHeads(num_classes=14)
+    finally:
+        TemporalRoIHeads.nms_prefix = 4096

@@ -1,0 +1,109 @@
+"""Full-size parity of the REAL drop-in forward: one 800x800 frame through ``model([img])`` -- 159 882 anchors, per-level
+top-1000, 5 x 1000 candidates into the RPN NMS, 1000 proposals through the box head, 13 x 1000 class candidates through the
+prefix NMS, top-100, mask + match branches, paste -- against the CPU oracle (ref models/video_matchrcnn.py:154-205,235-314).
+
+Proposals and detections are compared as EXACT sets (same label, coordinates within 0.05 px, scores within 1e-4) up to a
+printed list of at most 5 near-tie flips per side (tests/parity_sets.py); descriptors / ROI features / masks of the paired
+detections within the north_star tolerance (1e-3 of scale)."""
+import pytest
+import torch
+
+import seam_match_rcnn_amd.synth as synth
+from conftest import to_torch
+from oracle import model as OM
+from parity_sets import assert_same_set
+from test_gpu_ops import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def world():
+    from seam_match_rcnn_amd.models.video_matchrcnn import videomatchrcnn_resnet50_fpn
+    sd = to_torch(synth.video_matchrcnn_state(5))
+    m = videomatchrcnn_resnet50_fpn(pretrained_backbone=False, num_classes=14)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    img = torch.from_numpy(synth.frames(300, 1, 800, 800)[0])
+    with torch.no_grad():
+        ofe, osz, opad = OM.extract_features([img], sd)                       # default transform: 800 / 1333
+        oprops, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
+        ref, _, _ = OM.video_matchrcnn_forward([img], sd)
+    return dict(m=m, sd=sd, img=img, ofe=ofe, osz=osz, oprops=oprops, ref=ref[0])
+
+
+def test_rpn_proposals_800(world):
+    m, o = world["m"], world["oprops"][0]
+    with torch.no_grad():
+        feats, sizes, orig, padded = m.extract_features([world["img"].to(DEV)])
+        p = m.rpn(feats, sizes, padded)[0].cpu()
+    assert tuple(padded) == (800, 800) and len(o) == 1000 and len(p) == 1000            # post-NMS top-n is full at this size
+    partner = assert_same_set(o, p, tol_px=1e-2, what="RPN proposals 800x800")
+    # ... and in the same objectness order, flips aside
+    ok = partner >= 0
+    assert int((partner[ok] == torch.arange(len(o))[ok]).sum()) >= len(o) - 10
+
+
+def _check_detections(out, ref, what):
+    assert set(out) == {"boxes", "labels", "scores", "masks", "match_features", "w", "b", "roi_features"}
+    partner = assert_same_set(ref["boxes"], out["boxes"], ref["labels"], out["labels"], ref["scores"], out["scores"], what=what)
+    ok = partner >= 0
+    g = partner[ok]
+    assert int(ok.sum()) >= 95
+    assert_close(out["scores"].cpu()[g], ref["scores"][ok], rtol=1e-4)
+    assert_close(out["match_features"].cpu()[g], ref["match_features"][ok], rtol=1e-3, atol_scale=1e-3)
+    assert_close(out["roi_features"].cpu()[g], ref["roi_features"][ok], rtol=1e-3, atol_scale=1e-3)
+    gm, om = out["masks"].cpu()[g], ref["masks"][ok]
+    assert gm.shape[1:] == (1, 800, 800)
+    assert float(((gm - om).abs() > 2e-3).float().mean()) < 1e-4           # paste: a box edge 1e-4 px off can move a border pixel
+    return partner
+
+
+def test_drop_in_forward_800(world):
+    m, ref = world["m"], world["ref"]
+    with torch.no_grad():
+        out = m([world["img"].to(DEV)])[0]
+    assert len(ref["scores"]) == 100 and len(out["scores"]) == 100
+    partner = _check_detections(out, ref, "detections 800x800 (prefix NMS, exact)")
+    # the reference's contract for 'roi_features': a fresh contiguous NCHW tensor (ref :314) -- reference-style consumers work
+    rf = out["roi_features"]
+    assert rf.is_contiguous() and rf.view(rf.shape[0], -1).shape == (100, 256 * 14 * 14)
+    assert torch.equal(out["w"].cpu(), world["sd"]["roi_heads.match_predictor.last.weight"])
+
+
+def test_prefix_nms_paths_agree_800(world):
+    """The detection NMS looks at the `nms_prefix` best candidates first and repeats on everything when that prefix cannot be
+    proven exact.  Force both outcomes at full size (13 000 candidates): prefix 64 cannot hold 100 survivors -> the full
+    13 000-candidate NMS runs; prefix 8192 is exact.  Both must give the default's detections bit for bit."""
+    m = world["m"]
+    heads = m.roi_heads
+    img = world["img"].to(DEV)
+    saved = heads.nms_prefix
+    try:
+        with torch.no_grad():
+            base = m([img])[0]
+            outs = {}
+            for prefix in (64, 8192):
+                heads.nms_prefix = prefix
+                outs[prefix] = m([img])[0]
+    finally:
+        heads.nms_prefix = saved
+    for prefix, o in outs.items():
+        for k in ("boxes", "labels", "scores", "match_features"):
+            assert torch.equal(o[k], base[k]), (prefix, k)
+    _check_detections(outs[64], world["ref"], "detections 800x800 (prefix too small -> full NMS)")
+
+
+def test_box_branch_on_oracle_proposals_800(world):
+    """Stage isolation: the device box branch fed the ORACLE's proposals -- no RPN flip can leak into the comparison."""
+    m = world["m"]
+    from oracle import model as OMm
+    with torch.no_grad():
+        feats, sizes, orig, padded = m.extract_features([world["img"].to(DEV)])
+        res = m.roi_heads.detect(feats, [world["oprops"][0].to(DEV)], sizes)[0]
+        ref = OMm.detect(world["ofe"], world["oprops"], world["osz"], world["sd"], 0.1)[0]
+    partner = assert_same_set(ref["boxes"], res["boxes"], ref["labels"], res["labels"], ref["scores"], res["scores"], tol_px=1e-2,
+                              max_flips=2, what="box branch on oracle proposals")
+    ok = partner >= 0
+    assert_close(res["scores"].cpu()[partner[ok]], ref["scores"][ok], rtol=1e-4)

@@ -210,11 +210,12 @@ def test_full_forward_with_rpn(model_and_state):
     assert len(out) == 2
     for o, r in zip(out, ref):
         assert set(o) >= {"boxes", "labels", "scores", "masks", "match_features", "w", "b", "roi_features"}
-        n = min(len(o["scores"]), len(r["scores"]))
-        assert abs(len(o["scores"]) - len(r["scores"])) <= 2
-        # detections are a discrete selection (top-k / NMS): compare the score profile and the
-        # boxes of the leading detections that agree
-        assert_close(o["scores"][:n // 2], r["scores"][:n // 2], rtol=5e-3)
+        # detections are a discrete selection (top-k / NMS): exact as a set up to a printed, bounded list of near-tie flips
+        from parity_sets import assert_same_set
+        partner = assert_same_set(r["boxes"], o["boxes"], r["labels"], o["labels"], r["scores"], o["scores"], max_flips=5,
+                                  what="full forward 192x256")
+        ok = partner >= 0
+        assert_close(o["scores"].cpu()[partner[ok]], r["scores"][ok], rtol=1e-4)
         assert o["roi_features"].shape[1:] == (256, 14, 14)
         assert o["masks"].shape[-2:] == imgs[0].shape[-2:]
 

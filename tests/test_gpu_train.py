@@ -139,6 +139,36 @@ def test_nlb_attnpool_backward(lens):
         close(gr, want, rtol=5e-4, atol_frac=5e-5, msg=nm, zero=ZERO_ALWAYS)
 
 
+@pytest.mark.parametrize("b,t", [(1, 10), (3, 4), (2, 1), (1, 33)])
+def test_nlb_module_grad_enabled_direct_call(b, t):
+    """``NONLocalBlock1D.forward`` called directly with autograd (ref models/nlb.py:66-101; the aggregator path is covered above):
+    z and every gradient against torch autograd through the oracle's closed form of the block."""
+    from seam_match_rcnn_amd.models.nlb import NONLocalBlock1D
+    sd = to_torch(synth.temporal_aggregator_state(12))
+    names = ["theta.weight", "theta.bias", "phi.weight", "phi.bias", "g.weight", "g.bias", "concat_project.0.weight", "W.weight", "W.bias"]
+    blk = NONLocalBlock1D(256, sub_sample=False, bn_layer=False)
+    blk.load_state_dict({k: sd["newnlb." + k] for k in names})
+    blk = blk.to(DEV).train()
+    x = rnd(30 + t, b, 256, t)
+    xd = x.clone().to(DEV).requires_grad_(True)
+    z = blk(xd)
+    assert z.requires_grad and z.shape == (b, 256, t)
+    dz = rnd(31 + t, b, 256, t)
+    z.backward(dz.to(DEV))
+    p = {("newnlb." + k): sd["newnlb." + k].clone().requires_grad_(True) for k in names}
+    xr = x.clone().requires_grad_(True)
+    zr = torch.stack([OH.nlb_closed_form(xr[i].t(), p).t() for i in range(b)])
+    zr.backward(dz)
+    close(z, zr, msg="z")
+    close(xd.grad, xr.grad, msg="dx")
+    got = dict(blk.named_parameters())
+    for k in names:
+        close(got[k].grad, p["newnlb." + k].grad, rtol=5e-4, atol_frac=5e-5, msg=k, zero=ZERO_ALWAYS)
+    # no grad needed -> the plain inference launch, same values
+    with torch.no_grad():
+        close(blk(x.to(DEV)), zr, msg="z (no_grad)")
+
+
 def make_heads(n_frames=3):
     from seam_match_rcnn_amd.models.match_head import MatchPredictor, TemporalAggregationNLB
     mp, ta = MatchPredictor(), TemporalAggregationNLB()
