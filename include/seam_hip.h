@@ -277,6 +277,22 @@ int seam_pair_topk_f32(const float* a, const float* b, const float* w, const flo
                        int64_t* idx, float* score, int Q, int G, int D, int k, float* ws,
                        seam_stream_t stream);
 
+/* The same ranking for a LARGE bank (configs[2]/[3]: G = 20 000 / 50 000) on the fp32 matrix cores: candidates are found with the
+ * expanded form of the logit difference (one [Q,256] x [256,G] v_mfma_f32_16x16x4_f32 GEMM + two rank-1 terms, per-query
+ * threshold from a 4096-row sample, no [Q,G] tensor in HBM), the k + margin best are re-scored with the direct form in the
+ * operation order of seam_pair_logits_f32, and a per-query rounding-error bound proves that no other product can enter the top k
+ * (a query that fails the proof is redone with the direct form over the whole bank).  idx / score are bit-identical to
+ * seam_pair_logits_f32 + seam_rank_topk_f32 (ref models/match_head.py:161-162; evaluate_movingfashion.py:94-100,263-269).
+ * Requires D == 256, G >= seam_pair_topk_mfma_min_gallery(), k <= seam_pair_topk_mfma_max_k(), 16-byte aligned a / b / ws;
+ * ws: >= seam_pair_topk_mfma_workspace_floats(Q,G,k) floats.  flags bit 0: direct-form path for every query (test hook).
+ * stats: device int[4] or NULL -- [0] queries that took the direct-form path, [1] largest candidate count, [2] overflowed lists. */
+int seam_pair_topk_mfma_min_gallery(void);
+int seam_pair_topk_mfma_max_k(void);
+int64_t seam_pair_topk_mfma_workspace_floats(int Q, int G, int k);
+int seam_pair_topk_mfma_f32(const float* a, const float* b, const float* w, const float* bias,
+                            int64_t* idx, float* score, int Q, int G, int D, int k, float* ws, int flags,
+                            int* stats, seam_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Detection post-processing [TV] + models/video_matchrcnn.py:154-205.
  * BoxCoder.decode (weights wx,wy,ww,wh; dw,dh clamped to log(1000/16)) + clip to image.

@@ -89,6 +89,10 @@ SIGNATURES = {
     "seam_box_iou_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_pair_topk_workspace_floats": (_i64, [_i, _i, _i]),
     "seam_pair_topk_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "seam_pair_topk_mfma_min_gallery": (_i, []),
+    "seam_pair_topk_mfma_max_k": (_i, []),
+    "seam_pair_topk_mfma_workspace_floats": (_i64, [_i, _i, _i]),
+    "seam_pair_topk_mfma_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "seam_decode_boxes_f32": (_i, [_p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _p]),
     "seam_nms_sorted_f32": (_i, [_p, _p, _i, _i, _f, _p, _p]),
     "seam_nms_sorted_topn_f32": (_i, [_p, _p, _i, _i, _f, _i, _p, _p]),

@@ -8,9 +8,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "seam_topk.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+using seam_topk::TopkShared;
+using seam_topk::block_topk;
 
 constexpr int D = 256;       // descriptor width
 constexpr int DI = 128;      // NLB inter channels
@@ -548,118 +553,6 @@ __global__ __launch_bounds__(256) void pair_logits_kernel(const float* __restric
             const int gj = g0 + tx + 32 * j;
             if (gj < G) *reinterpret_cast<f32x2*>(out + ((size_t)qi * G + gj) * 2) = acc[i][j] + bz;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Exact top-k of one row of n (x0, x1) pairs under the strict order (d = x1 - x0 descending, index
-// ascending), O(n) instead of k arg-max rounds: an MSB-first 8-bit radix select over order-preserving
-// keys finds the k-th largest key T (4 histogram passes in LDS), everything above T is collected with
-// one pass, ties at T are taken lowest-index-first, and the k winners are ordered by rank counting.
-// Item j of the row is (x0, x1, g) = load(j); g is the value reported as its index.
-__device__ __forceinline__ unsigned tk_key(float x0, float x1) {
-    float d = x1 - x0;
-    if (d != d) d = -INFINITY;                   // NaN ranks last
-    d += 0.f;                                    // -0 -> +0 (equal scores must tie)
-    const unsigned u = __float_as_uint(d);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-struct TopkShared {
-    unsigned hist[256];
-    unsigned key[256];
-    int item[256];
-    int gidx[256];
-    unsigned prefix, krem, cnt;
-    int red[4];
-};
-
-template <typename Load>
-__device__ void block_topk(Load load, int n, int k, int64_t* __restrict__ idx_out, float* __restrict__ score_out,
-                           TopkShared& sh) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    unsigned prefix = 0, mask = 0, krem = (unsigned)k;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        sh.hist[tid] = 0;
-        __syncthreads();
-        for (int j = tid; j < n; j += 256) {
-            float x0, x1; int g;
-            load(j, x0, x1, g);
-            const unsigned key = g < 0 ? 0u : tk_key(x0, x1);
-            if (g >= 0 && (key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned cum = 0;
-            int bsel = 0;
-            for (int bb = 255; bb >= 0; --bb) {
-                if (cum + sh.hist[bb] >= krem) { bsel = bb; break; }
-                cum += sh.hist[bb];
-            }
-            sh.prefix = prefix | ((unsigned)bsel << shift);
-            sh.krem = krem - cum;
-        }
-        __syncthreads();
-        prefix = sh.prefix;
-        krem = sh.krem;
-        mask |= 0xFFu << shift;
-    }
-    const unsigned T = prefix;                   // k-th largest key; krem (>= 1) of the items equal to T are taken
-    const int nabove = k - (int)krem;
-    if (tid == 0) sh.cnt = 0;
-    __syncthreads();
-    for (int j = tid; j < n; j += 256) {
-        float x0, x1; int g;
-        load(j, x0, x1, g);
-        if (g < 0) continue;
-        const unsigned key = tk_key(x0, x1);
-        if (key > T) {
-            const unsigned pos = atomicAdd(&sh.cnt, 1u);
-            sh.key[pos] = key; sh.item[pos] = j; sh.gidx[pos] = g;
-        }
-    }
-    __syncthreads();
-    int last = -1;
-    for (unsigned r = 0; r < krem; ++r) {        // ties at T: lowest reported index first (usually one round)
-        int best = 0x7fffffff, bestj = -1;
-        for (int j = tid; j < n; j += 256) {
-            float x0, x1; int g;
-            load(j, x0, x1, g);
-            if (g > last && g < best && tk_key(x0, x1) == T) { best = g; bestj = j; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int ob = __shfl_xor(best, o, 64), oj = __shfl_xor(bestj, o, 64);
-            if (ob < best) { best = ob; bestj = oj; }
-        }
-        if (lane == 0) { sh.red[wid] = best; sh.hist[wid] = (unsigned)bestj; }
-        __syncthreads();
-        if (tid == 0) {
-            int bb = sh.red[0], bj = (int)sh.hist[0];
-            for (int w2 = 1; w2 < 4; ++w2)
-                if (sh.red[w2] < bb) { bb = sh.red[w2]; bj = (int)sh.hist[w2]; }
-            sh.key[nabove + r] = T; sh.item[nabove + r] = bj; sh.gidx[nabove + r] = bb;
-            sh.red[0] = bb;
-        }
-        __syncthreads();
-        last = sh.red[0];
-        __syncthreads();
-    }
-    if (tid < k) {                               // order the k winners by counting (k <= 256)
-        const unsigned mk = sh.key[tid];
-        const int mg = sh.gidx[tid], mj = sh.item[tid];
-        int rank = 0;
-        for (int j = 0; j < k; ++j) rank += (sh.key[j] > mk || (sh.key[j] == mk && sh.gidx[j] < mg)) ? 1 : 0;
-        float sc = 0.f;
-        if (mj >= 0) {
-            float x0, x1; int g;
-            load(mj, x0, x1, g);
-            const float mx = fmaxf(x0, x1);
-            const float e0 = expf(x0 - mx), e1 = expf(x1 - mx);
-            sc = e1 / (e0 + e1);                 // softmax(x)[1]
-        }
-        idx_out[rank] = mj >= 0 ? (int64_t)mg : (int64_t)-1;
-        score_out[rank] = sc;
     }
 }
 

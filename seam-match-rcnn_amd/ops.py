@@ -809,20 +809,40 @@ def box_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pair_topk(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, k: int, fused: bool = False,
-              q_chunk: int = 64):
-    """a13+a14 without materialising the full [Q,G,2] logits -> (idx int64 [Q,k], score [Q,k]).
+PAIR_MFMA = True       # large banks: candidates on the fp32 matrix cores (seam_pair_topk_mfma_f32); False: the chunked VALU path
 
-    Default: query chunks of ``q_chunk`` through seam_pair_logits_f32 + seam_rank_topk_f32 with one reused
-    logits buffer (q_chunk*G*8 bytes, cache resident).  On MI355X this beats the single-pass kernel
-    (``fused=True`` -> seam_pair_topk_f32) because in exact fp32 the stage is VALU-bound, not HBM-bound:
-    config 3 = 165 us logits + 168 us ranking vs 590 us fused; both give bit-identical rankings."""
+
+def pair_topk(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, k: int, fused: bool = False,
+              q_chunk: int = 64, mfma: Optional[bool] = None, stats: Optional[torch.Tensor] = None, force_exact: bool = False):
+    """a13+a14 without materialising the full [Q,G,2] logits -> (idx int64 [Q,k], score [Q,k]).  Three implementations with
+    bit-identical results:
+
+    * ``mfma`` (default when the bank has >= seam_pair_topk_mfma_min_gallery() rows, D == 256, k <= 64): seam_pair_topk_mfma_f32 --
+      the logit-difference GEMM on the fp32 matrix cores finds candidates, the winners are re-scored with the direct form and a
+      per-query error bound proves the top k (``stats``: optional int32[4] device tensor that receives [queries redone with the
+      direct form, largest candidate list, overflowed lists, 0]; ``force_exact``: test hook, every query takes the direct form);
+    * query chunks of ``q_chunk`` through seam_pair_logits_f32 + seam_rank_topk_f32 with one reused logits buffer (small banks);
+    * ``fused=True``: seam_pair_topk_f32, the single-pass VALU kernel."""
     lib = _native.lib()
     a, b, w, bias = _req(a), _req(b), _req(w.detach()), _req(bias.detach())
     q, g, d = a.shape[0], b.shape[0], a.shape[1]
     k = min(k, g)
     idx = torch.empty((q, k), dtype=torch.int64, device=a.device)
     sc = torch.empty((q, k), dtype=F32, device=a.device)
+    can_mfma = d == 256 and g >= lib.seam_pair_topk_mfma_min_gallery() and 0 < k <= lib.seam_pair_topk_mfma_max_k() and q > 0
+    if mfma is None:
+        mfma = PAIR_MFMA and can_mfma and not fused
+    if mfma:
+        if not can_mfma:
+            raise ValueError(f"pair_topk(mfma=True) needs D == 256, G >= {lib.seam_pair_topk_mfma_min_gallery()} and "
+                             f"k <= {lib.seam_pair_topk_mfma_max_k()} (got D={d}, G={g}, k={k})")
+        ws = torch.empty((int(lib.seam_pair_topk_mfma_workspace_floats(q, g, k)),), dtype=F32, device=a.device)
+        if stats is not None:
+            stats = _req(stats, torch.int32, "stats")
+        _native.check(lib.seam_pair_topk_mfma_f32(_ptr(a), _ptr(b), _ptr(w), _ptr(bias), _ptr(idx), _ptr(sc), q, g, d, k, _ptr(ws),
+                                                  1 if force_exact else 0, _ptr(stats) if stats is not None else None, _stream()),
+                      "seam_pair_topk_mfma_f32")
+        return idx, sc
     if fused:
         ws = torch.empty((int(lib.seam_pair_topk_workspace_floats(q, g, k)),), dtype=F32, device=a.device)
         _native.check(lib.seam_pair_topk_f32(_ptr(a), _ptr(b), _ptr(w), _ptr(bias), _ptr(idx), _ptr(sc), q, g, d, k,
