@@ -66,6 +66,7 @@ SIGNATURES = {
     "seam_maxpool2d_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_upsample_add_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_roi_align_f16": (_i, [_p, _p, _p, _p, C.POINTER(_i), _i, _f, _f, _f, _f, _i, _p, _p, _p, _i, _i, _i, _p]),
+    "seam_roi_align_set_lds": (None, [_i]),
     "seam_nchw_f32_to_nhwc_f16": (_i, [_p, _p, _i, _i, _i, _p]),
     "seam_nhwc_f16_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "seam_avgpool_f16": (_i, [_p, _p, _i, _i, _i, _p]),

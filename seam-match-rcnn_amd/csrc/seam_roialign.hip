@@ -1,11 +1,21 @@
 // seam_roialign.hip -- MultiScaleRoIAlign + roi_align(aligned=False) on NHWC pyramids (gfx950).
 //
-// One wave64 per output bin: lane l owns channels [4l,4l+4) (+256 per extra pass), so each of the
-// 16 bilinear taps of a bin is ONE coalesced 1 KiB wave load (channels are contiguous in NHWC);
-// neighbouring bins/ROIs re-hit the taps in L1/L2.  Sample coordinates are wave-uniform.
-// Gather-bound: 0.80 M tap loads per 14x14 ROI vs 200 704 B written.
+// Two kernels, bit-identical results (the same expression per sample, in the same order):
+//
+// roi_align_kernel      one wave64 per output bin: lane l owns channels [4l,4l+4) (+256 per extra pass), so each of the
+//                       16 bilinear taps of a bin is ONE coalesced 1 KiB wave load (channels are contiguous in NHWC);
+//                       neighbouring bins/ROIs re-hit the taps in L1/L2.  Sample coordinates are wave-uniform.
+//                       Gather-bound: 0.80 M tap loads per 14x14 ROI vs 200 704 B written.
+// roi_align_lds_kernel  LDS-staged ROI tiles (what BASELINE.json's north_star names): one block per (ROI, 64-channel quarter);
+//                       for every row of bins the (at most four) feature rows its two sample rows touch are read ONCE, as
+//                       contiguous row segments (ROI width x 256 B), into LDS through a register-staged prefetch that runs one
+//                       bin row ahead; the 14 bins x 16 taps then come from LDS (conflict-free ds_read_b128: the 16 lanes of a
+//                       read group hold the 16 channel groups).  L2 -> CU traffic per ROI drops from 16 taps x 196 bins x 1 KiB
+//                       = 3.2 MB to about 1.3 x the ROI's footprint.  sampling_ratio 2, P <= 16, C % 64 == 0; ROIs wider than
+//                       40 feature pixels take the gather path inside the same kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -28,6 +38,15 @@ __device__ __forceinline__ int map_level(float x1, float y1, float x2, float y2,
     float l = floorf(4.f + log2f(s / 224.f) + 1e-6f);
     l = fminf(fmaxf(l, (float)k_min), (float)(k_min + 3));
     return (int)l - k_min;
+}
+
+// one bilinear sample, fixed operation order (both kernels): acc + (((w1 v1) + w2 v2) + w3 v3) + w4 v4, each "+ w v" one fma
+__device__ __forceinline__ f32x4 sample_acc(f32x4 acc, float w1, f32x4 v1, float w2, f32x4 v2, float w3, f32x4 v3, float w4, f32x4 v4) {
+    f32x4 s = w1 * v1;
+    s = __builtin_elementwise_fma((f32x4){w2, w2, w2, w2}, v2, s);
+    s = __builtin_elementwise_fma((f32x4){w3, w3, w3, w3}, v3, s);
+    s = __builtin_elementwise_fma((f32x4){w4, w4, w4, w4}, v4, s);
+    return acc + s;
 }
 
 template <typename T>
@@ -79,7 +98,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
                 const tv4 t4 = *reinterpret_cast<const tv4*>(f + ((size_t)yh * W + xh) * p.C + c0);
                 const f32x4 v1 = __builtin_convertvector(t1, f32x4), v2 = __builtin_convertvector(t2, f32x4);
                 const f32x4 v3 = __builtin_convertvector(t3, f32x4), v4 = __builtin_convertvector(t4, f32x4);
-                acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                acc = sample_acc(acc, w1, v1, w2, v2, w3, v3, w4, v4);
             }
         }
         acc /= cnt;
@@ -87,7 +106,143 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
     }
 }
 
+constexpr int RA_WCAP = 40;      // feature pixels per staged row segment (40 KB of LDS per fp32 block: four blocks per CU)
+constexpr int RA_CB = 64;        // channels per block
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_lds_kernel(const RoiArgs p) {
+    typedef T tv4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) T rows[4][RA_WCAP][RA_CB];
+    const int tid = threadIdx.x, cg = tid & 15, pw = tid >> 4;
+    const int nq = p.C / RA_CB;
+    const int k = blockIdx.x / nq, c0 = (blockIdx.x - k * nq) * RA_CB + cg * 4;
+
+    const float* r = p.rois + (size_t)k * 5;
+    const int bidx = (int)r[0];
+    const float bx1 = r[1], by1 = r[2], bx2 = r[3], by2 = r[4];
+    const int lvl = p.levels ? p.levels[k] : map_level(bx1, by1, bx2, by2, p.k_min);
+    const int H = lvl == 0 ? p.h[0] : lvl == 1 ? p.h[1] : lvl == 2 ? p.h[2] : p.h[3];
+    const int W = lvl == 0 ? p.w[0] : lvl == 1 ? p.w[1] : lvl == 2 ? p.w[2] : p.w[3];
+    const float sc = lvl == 0 ? p.scale[0] : lvl == 1 ? p.scale[1] : lvl == 2 ? p.scale[2] : p.scale[3];
+    const T* fb = (const T*)(lvl == 0 ? p.feat[0] : lvl == 1 ? p.feat[1] : lvl == 2 ? p.feat[2] : p.feat[3]);
+    const T* f = fb + (size_t)bidx * H * W * p.C;
+
+    const float x1 = bx1 * sc, y1 = by1 * sc, x2 = bx2 * sc, y2 = by2 * sc;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    const float bw = rw / (float)p.P, bh = rh / (float)p.P;
+    const float cnt = 4.f;
+
+    // column range of the taps of all samples of a bin row (the same for every row); the sample abscissae are increasing
+    auto tap_x = [&](float x, int& xl, int& xh, float& xx) {
+        xx = fmaxf(x, 0.f);
+        xl = (int)xx;
+        if (xl >= W - 1) { xl = xh = W - 1; xx = (float)xl; } else { xh = xl + 1; }
+    };
+    int xlo, xhi;
+    {
+        float t;
+        int a, b;
+        tap_x(x1 + (float)0 * bw + ((float)0 + 0.5f) * bw / 2.f, xlo, a, t);
+        tap_x(x1 + (float)(p.P - 1) * bw + ((float)1 + 0.5f) * bw / 2.f, b, xhi, t);
+    }
+    const int wpx = xhi - xlo + 1;
+    const bool staged = wpx <= RA_WCAP;           // block-uniform
+    const int per_row = wpx * (RA_CB / 4);        // 16-byte vectors per staged row segment
+    const int total = 4 * per_row;
+
+    // rows of bin row ph: (yl, yh) of its two sample rows, as the gather kernel computes them
+    auto tap_y = [&](int ph, int iy, int& yl, int& yh, float& yy, bool& ok) {
+        const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / 2.f;
+        ok = !(y < -1.f || y > (float)H);
+        yy = fmaxf(y, 0.f);
+        yl = (int)yy;
+        if (yl >= H - 1) { yl = yh = H - 1; yy = (float)yl; } else { yh = yl + 1; }
+    };
+    constexpr int NST = 4 * RA_WCAP * (RA_CB / 4) / 256;      // staging vectors per thread
+    tv4 st[NST];
+    // which vector of which staged row each of this thread's staging slots moves: fixed for the whole ROI (only the row numbers
+    // change from bin row to bin row), so the divisions are done once
+    int g_off[NST], l_off[NST], s_row[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int v = min(tid + 256 * i, total - 1);   // slots past the segment re-read its last vector and are never stored
+        const int rr = v / per_row, rem = v - rr * per_row, px = rem >> 4, c4 = rem & 15;
+        s_row[i] = rr;
+        g_off[i] = (xlo + px) * p.C + (c0 - cg * 4) + c4 * 4;
+        l_off[i] = (tid + 256 * i < total) ? (rr * RA_WCAP + px) * RA_CB + c4 * 4 : -1;
+    }
+    auto prefetch = [&](int ph) {
+        int yr[4];
+        float t;
+        bool ok;
+        tap_y(ph, 0, yr[0], yr[1], t, ok);
+        tap_y(ph, 1, yr[2], yr[3], t, ok);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {               // unconditional loads (a branch around a load serialises it behind vmcnt(0))
+            const int row = s_row[i] == 0 ? yr[0] : s_row[i] == 1 ? yr[1] : s_row[i] == 2 ? yr[2] : yr[3];
+            st[i] = *reinterpret_cast<const tv4*>(f + (size_t)row * W * p.C + g_off[i]);
+        }
+    };
+    auto commit = [&]() {
+        T* base = &rows[0][0][0];
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (l_off[i] >= 0) *reinterpret_cast<tv4*>(base + l_off[i]) = st[i];
+    };
+
+    if (staged) prefetch(0);
+    for (int ph = 0; ph < p.P; ++ph) {
+        if (staged) {
+            __syncthreads();                       // the previous bin row's reads of `rows` are done
+            commit();
+            __syncthreads();
+            if (ph + 1 < p.P) prefetch(ph + 1);    // in flight under this bin row's arithmetic
+        }
+        if (pw < p.P) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+                int yl, yh;
+                float yy;
+                bool yok;
+                tap_y(ph, iy, yl, yh, yy, yok);
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / 2.f;
+                    if (!yok || x < -1.f || x > (float)W) continue;
+                    int xl, xh;
+                    tap_x(x, xl, xh, x);
+                    const float ly = yy - (float)yl, lx = x - (float)xl;
+                    const float hy = 1.f - ly, hx = 1.f - lx;
+                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                    tv4 t1, t2, t3, t4;
+                    if (staged) {
+                        t1 = *reinterpret_cast<const tv4*>(&rows[2 * iy][xl - xlo][cg * 4]);
+                        t2 = *reinterpret_cast<const tv4*>(&rows[2 * iy][xh - xlo][cg * 4]);
+                        t3 = *reinterpret_cast<const tv4*>(&rows[2 * iy + 1][xl - xlo][cg * 4]);
+                        t4 = *reinterpret_cast<const tv4*>(&rows[2 * iy + 1][xh - xlo][cg * 4]);
+                    } else {
+                        t1 = *reinterpret_cast<const tv4*>(f + ((size_t)yl * W + xl) * p.C + c0);
+                        t2 = *reinterpret_cast<const tv4*>(f + ((size_t)yl * W + xh) * p.C + c0);
+                        t3 = *reinterpret_cast<const tv4*>(f + ((size_t)yh * W + xl) * p.C + c0);
+                        t4 = *reinterpret_cast<const tv4*>(f + ((size_t)yh * W + xh) * p.C + c0);
+                    }
+                    const f32x4 v1 = __builtin_convertvector(t1, f32x4), v2 = __builtin_convertvector(t2, f32x4);
+                    const f32x4 v3 = __builtin_convertvector(t3, f32x4), v4 = __builtin_convertvector(t4, f32x4);
+                    acc = sample_acc(acc, w1, v1, w2, v2, w3, v3, w4, v4);
+                }
+            }
+            acc /= cnt;
+            *reinterpret_cast<tv4*>((T*)p.out + ((size_t)k * p.P * p.P + (size_t)ph * p.P + pw) * p.C + c0) = __builtin_convertvector(acc, tv4);
+        }
+    }
+}
+
+int g_roi_lds = -1;              // -1: read SEAM_ROIALIGN_LDS on first use (default OFF: the gather kernel measured faster, profiles/r03_roialign_ab.txt)
+
 }  // namespace
+
+extern "C" void seam_roi_align_set_lds(int on) { g_roi_lds = on ? 1 : 0; }
 
 template <typename T>
 static int roi_align_launch(const void* feat0, const void* feat1, const void* feat2, const void* feat3, const int* hw, int C,
@@ -101,6 +256,14 @@ static int roi_align_launch(const void* feat0, const void* feat1, const void* fe
     a.scale[0] = scale0; a.scale[1] = scale1; a.scale[2] = scale2; a.scale[3] = scale3;
     a.C = C; a.k_min = k_min; a.rois = rois; a.levels = levels; a.out = out; a.K = K; a.P = P;
     a.sr = sampling_ratio;
+    if (g_roi_lds < 0) {
+        const char* e = getenv("SEAM_ROIALIGN_LDS");
+        g_roi_lds = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (g_roi_lds && sampling_ratio == 2 && P <= 16 && (C % RA_CB) == 0) {
+        hipLaunchKernelGGL(roi_align_lds_kernel<T>, dim3((unsigned)((long)K * (C / RA_CB))), dim3(256), 0, (hipStream_t)stream, a);
+        return (int)hipGetLastError();
+    }
     const long bins = (long)K * P * P;
     hipLaunchKernelGGL(roi_align_kernel<T>, dim3((unsigned)((bins + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();

@@ -289,6 +289,32 @@ def test_roi_align_multiscale(ops):
         assert_close(out.permute(0, 3, 1, 2), ref, atol_scale=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_roi_align_lds_tiles_equal_the_gather_kernel(ops, dtype):
+    """The LDS-staged ROI-tile kernel and the one-wave-per-bin gather kernel evaluate the same expression per sample in the same
+    order: bit-identical outputs -- on the config-2 ROI set, on boxes hanging over every image edge, degenerate boxes, and a box
+    wider than the 64-pixel staging window (gather path inside the LDS kernel)."""
+    from seam_match_rcnn_amd import _native
+    d = dev()
+    feats = [nhwc(rnd(140 + i, (2, 256, h, w))).to(d).to(dtype) for i, (h, w) in enumerate(((200, 336), (100, 168), (50, 84), (25, 42)))]
+    boxes = torch.cat([torch.from_numpy(synth.fixed_rois(32, 800, 800)),
+                       torch.tensor([[-30., -20., 90., 70.], [700., 750., 1400., 900.], [5., 5., 5.5, 5.2], [0., 0., 1344., 800.],
+                                     [10., 300., 1330., 340.],          # 1320 px wide, 40 tall: level 2 (stride 4) -> 330 feature px
+                                     [600., -100., 640., 900.], [1340., 790., 1344., 800.], [200.3, 100.7, 457.9, 388.1]])])
+    rois = torch.cat([torch.cat([torch.full((len(boxes), 1), float(i)), boxes], 1) for i in range(2)]).to(d)
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    lib = _native.lib()
+    try:
+        for pooled in (14, 7):
+            lib.seam_roi_align_set_lds(0)
+            ref = ops.roi_align(feats, rois, scales, pooled)
+            lib.seam_roi_align_set_lds(1)
+            out = ops.roi_align(feats, rois, scales, pooled)
+            assert torch.equal(out, ref), (pooled, float((out.float() - ref.float()).abs().max()))
+    finally:
+        lib.seam_roi_align_set_lds(0)
+
+
 def test_nlb_attnpool_golden_and_oracle(ops, golden):
     d = dev()
     from seam_match_rcnn_amd.models.match_head import pack_nlb_from_state
