@@ -411,13 +411,39 @@ def main():
                                      "full_forward_ms_per_clip: median of 3 of model(10 frames) with RPN proposals, box head, "
                                      "per-class NMS, mask + match branches and mask paste (not part of `value`)")
 
+    match_stage = None
+    if rank == 0 and not stub and wl["rank"] == "topk" and not args.graph:
+        # configs[2]/[3]: the similarity + top-k stage on its own (HIP events on the launch stream), this rank's sequences vs the bank
+        with torch.no_grad():
+            desc, bank = last[1][0].contiguous(), last[5]
+            stats = torch.zeros(4, dtype=torch.int32, device=dev)
+            for _ in range(3):
+                ops.pair_topk(desc, bank, ta.last.weight, ta.last.bias, TOPK, stats=stats)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                ops.pair_topk(desc, bank, ta.last.weight, ta.last.bias, TOPK, stats=stats)
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / reps
+            q, g = desc.shape[0], bank.shape[0]
+            gemm = 2.0 * q * g * 256 / us / 1e6
+            match_stage = {"kernel": "seam_pair_topk_mfma_f32 (prep + sample GEMM + thresholds + filter GEMM + exact re-score / proof)",
+                           "queries": q, "gallery": g, "topk": TOPK, "us_per_call": round(us, 1),
+                           "gemm_tflops": round(gemm, 1), "frac_of_fp32_mfma_peak": round(gemm / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "gemm_flops_are": "2*Q*G*256 of the logit-difference GEMM (the direct form the oracle evaluates is 1536 FLOP per pair)",
+                           "direct_form_equivalent_tflops": round(1536.0 * q * g / us / 1e6, 1),
+                           "queries_redone_with_the_direct_form": int(stats[0]), "largest_candidate_list": int(stats[1]),
+                           "bit_identical_to": "seam_pair_logits_f32 + seam_rank_topk_f32 (tests/test_gpu_pairmf.py)"}
+
     failed = None
     if rank == 0:
         what = (f"{wl['cfg']} full pipeline, fixed ROIs: {T} frames {H}x{W} -> ResNet-50-FPN + RPN head "
                 f"-> RoIAlign 14x14 ({R} ROI/frame) -> mask head -> match trunk x2 -> SEAM NLB + "
                 f"attention pool ({R} seq x {T}) -> " +
                 (f"pair logits vs {G}-product bank -> top-{TOPK}" if wl["rank"] == "logits" else
-                 f"pair logits + top-{TOPK} vs {G}-product bank in query chunks (no [S,G,2] tensor in HBM)"))
+                 f"MFMA similarity + fused top-{TOPK} vs {G}-product bank (no [S,G,2] tensor in HBM)"))
         gal = {1000: "1k", 20000: "20k", 50000: "50k"}[G]
         metric = (f"video-clips/sec (10f x 800^2, 32 ROI/f, {gal} gallery)" if args.workload != "c5"
                   else "video-clips/sec (30f x 1080p, 64 ROI/f, 1k gallery)")
@@ -440,6 +466,8 @@ def main():
                 failed = "the all-gathered product bank differs between ranks"
         if allgather is not None:
             line["allgather"] = allgather
+        if match_stage is not None:
+            line["match_stage"] = match_stage
         if roofline is not None:
             line["roofline"] = roofline
         if cpu is not None:
@@ -522,6 +550,17 @@ def roofline_leg(step, dtype):
                                for k, v in per.items() if k != dom}}
 
 
+def csrc_digest():
+    """Identity of the convolution kernels' sources (the kernels the roofline leg reports): sha256 over the three files that define
+    them (name + bytes)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("seam_conv.hip", "seam_wino.hip", "seam_wino24.hip"):
+        h.update(name.encode())
+        h.update(open(os.path.join(ROOT, "seam-match-rcnn_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_fields(kernel):
     """(source, traffic, mfma_busy) of `kernel` from the newest COMMITTED rocprofv3 PMC passes (profiles/*_pmc_traffic.json, made
     by tools/pmc_bench_traffic.sh over this same bench command on an earlier run -- NOT measured in this process; `source`
@@ -550,6 +589,12 @@ def pmc_fields(kernel):
                   "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per launch"}
     if isinstance(d.get("_meta"), dict):
         src.update(d["_meta"])
+    # the counters describe the kernels of the tree they were collected on: a file from other kernel sources is named, not used
+    src["csrc_digest_now"] = csrc_digest()
+    src["matches_current_sources"] = src.get("csrc_digest") == src["csrc_digest_now"]
+    if not src["matches_current_sources"]:
+        src["stale"] = "collected on different kernel sources: traffic / mfma_busy_frac_pmc withheld (re-run tools/pmc_bench_traffic.sh)"
+        traffic = busy = None
     return src, traffic, busy
 
 

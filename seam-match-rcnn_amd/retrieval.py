@@ -145,9 +145,11 @@ def match_sequences(aggregator, x3_1b: torch.Tensor, bank: torch.Tensor, k: int 
 
 @torch.no_grad()
 def match_sequences_topk(aggregator, x3_1b: torch.Tensor, bank: torch.Tensor, k: int = 20):
-    """Same ranking as ``match_sequences`` without materialising the full [S,G,2] logits (query chunks
-    through a reused, cache-resident logits buffer; see ``ops.pair_topk``) for large galleries
-    (configs 3/4: G = 20 000 / 50 000).  -> (idx [S,k] int64, score [S,k])."""
+    """Same ranking as ``match_sequences`` without materialising the full [S,G,2] logits, for large galleries (configs 3/4:
+    G = 20 000 / 50 000): ``ops.pair_topk`` -- banks of >= 8192 products go through the MFMA similarity + fused top-k
+    (seam_pair_topk_mfma_f32: candidates from the logit-difference GEMM, exact re-scoring, rounding-error proof), smaller ones
+    through query chunks of seam_pair_logits_f32 + seam_rank_topk_f32; bit-identical either way.
+    -> (idx [S,k] int64, score [S,k])."""
     from . import ops
     return ops.pair_topk(x3_1b, bank, aggregator.last.weight, aggregator.last.bias, min(k, bank.shape[0]))
 

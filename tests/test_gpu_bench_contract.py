@@ -44,7 +44,10 @@ def test_bench_line_and_roofline_fields():
     else:
         assert r["mfma_issue_ratio"] == 1.0
     assert r["traffic"] is None or (r["traffic"] > 0 and r["pmc_source"]["file"].startswith("profiles/")
-                                    and r["pmc_source"]["measured_in_this_run"] is False)
+                                    and r["pmc_source"]["measured_in_this_run"] is False
+                                    and r["pmc_source"]["matches_current_sources"] is True)
+    if r["pmc_source"] is not None and not r["pmc_source"]["matches_current_sources"]:
+        assert r["traffic"] is None and r["mfma_busy_frac_pmc"] is None and "stale" in r["pmc_source"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "clips/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert len(c["runs_s"]) == 3 and c["cpu"]              # 1 warm-up + min of 2 here (--cpu-runs 2)
@@ -61,7 +64,9 @@ def test_bench_large_gallery_workload_c3():
     d = run([sys.executable, "bench.py", "--workload", "c3", "--steps", "2", "--warmup", "1", "--clips", "1", "--cpu-frames", "1",
              "--cpu-runs", "1", "--no-roofline"])
     assert d["config"]["gallery"] == 20000 and "20k gallery" in d["metric"] and "configs[2]" in d["config"]["workload"]
-    assert d["parity"]["ok"] is True and d["parity"]["topk_set_overlap"] >= 0.99
+    assert d["parity"]["ok"] is True and d["parity"]["topk_set_overlap"] >= 0.99 and d["parity"]["topk_equal"] is True
+    m = d["match_stage"]                              # the MFMA similarity + top-k stage, timed on its own
+    assert m["queries"] == 32 and m["gallery"] == 20000 and 0 < m["us_per_call"] < 500 and m["queries_redone_with_the_direct_form"] == 0
 
 
 def test_bench_under_the_multi_gpu_launcher():

@@ -42,8 +42,10 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "SQ_BUSY_CU_CYCLES" in out:
     # matrix-pipe busy fraction while the CU is busy: MFMA busy cycles are counted per SIMD (4 per CU)
     out["mfma_busy_frac"] = {k: round(out["SQ_VALU_MFMA_BUSY_CYCLES"][k]["total"] / (4.0 * out["SQ_BUSY_CU_CYCLES"][k]["total"]), 4)
                              for k in out["SQ_VALU_MFMA_BUSY_CYCLES"] if k in out["SQ_BUSY_CU_CYCLES"]}
-import subprocess, datetime
-out["_meta"] = {"tag": "$TAG", "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+import subprocess, datetime, sys
+sys.path.insert(0, "$R")
+import bench
+out["_meta"] = {"tag": "$TAG", "csrc_digest": bench.csrc_digest(), "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
                 "command": "rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --single-stream"}
 json.dump(out, open("$R/gpurun_out/pmc_traffic_$TAG.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k in ("mfma_busy_frac",)}, indent=1))

@@ -17,6 +17,12 @@ python3 $R/bench.py --dtype f16 --workload c5 --no-cpu-baseline --steps 5 --warm
 python3 $R/bench.py --graph --clips 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_graph.json 2>/dev/null
 python3 $R/bench.py --clips 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_clips1.json 2>/dev/null
 bash $R/tools/pmc_bench_traffic.sh ${TAG}_bf16x3 --dtype bf16x3 > $O/${TAG}_pmc_bf16x3.log 2>&1
+python3 $R/tools/heads_bench.py > $O/${TAG}_heads_bench.txt 2>/dev/null
+for G in 20000 50000; do
+  rm -rf /tmp/pmf_$TAG
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmf_$TAG -o p -- python3 $R/tools/pairmf_bench.py 256 $G > $O/${TAG}_pairmf_${G}.txt 2>/dev/null
+  (cat /tmp/pmf_$TAG/p_kernel_stats.csv 2>/dev/null || cat /tmp/pmf_$TAG/*/p_kernel_stats.csv) > $O/${TAG}_pairmf_${G}_kernel_stats.csv
+done
 python3 $R/tools/train_bench.py 8 10 > $O/${TAG}_train_bench.txt 2>/dev/null
 python3 $R/tools/full_forward_timing.py > $O/${TAG}_full_forward.txt 2>/dev/null
 ls -la $O | grep $TAG
