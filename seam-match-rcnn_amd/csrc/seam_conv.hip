@@ -69,6 +69,7 @@ struct ConvArgs {
     // div_fast is set (Ho*Wo*Wo < 2^32; the host checks).  A tile's rows are first made local to its first image.
     unsigned m_HoWo, m_Wo;
     int div_fast;
+    int epi_prio;      // 1: s_setprio 3 for the epilogue (dev knob SEAM_EPI_PRIO=0 turns it off)
     int rH, rW;        // > 0 (fp32, K % 4 == 0 only): `res` is a coarser map [N, rH, rW, K] added through a nearest-neighbour
                        // upsample to [Ho, Wo] (ATen: src = min(floor(dst * rH / Ho), rH - 1)) -- the FPN top-down merge
 };
@@ -371,6 +372,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
     //  hoisted out of the persistent loop, where 64 of them would stay live across the K loop)
     int lq = lane;
     asm volatile("" : "+v"(lq));
+    // The epilogue at raised wave priority: beside a co-resident block that is streaming MFMAs, its ~300 instructions otherwise
+    // issue one per MFMA of the partner (measured: 19-24 k cycles per epilogue, profiles/r03_igemm_swap_and_tile_timeline.txt)
+    if (p.epi_prio) __builtin_amdgcn_s_setprio(3);
     const int YS = (F16 && !p.y_f32) ? 2 : 4;       // output element size
     const size_t tile_off = (size_t)cm0 * p.K;
     const unsigned rows_here = (unsigned)min(BM, p.M - cm0);
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_igemm(const Con
             }
         }
     }
+    if (p.epi_prio) __builtin_amdgcn_s_setprio(0);
     if constexpr (!PREFETCH) next_tile();
     }   // persistent tile loop
 }
@@ -1017,6 +1022,8 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.y_f32 = y_f32;
     static const int vec_epi = getenv("SEAM_F16_VEC_EPILOGUE") ? atoi(getenv("SEAM_F16_VEC_EPILOGUE")) : 1;
     a.vec_epi = vec_epi;
+    static const int epi_prio = getenv("SEAM_EPI_PRIO") ? atoi(getenv("SEAM_EPI_PRIO")) : 1;
+    a.epi_prio = epi_prio;
 
     a.rH = rH; a.rW = rW;
     a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
@@ -1083,6 +1090,7 @@ int conv2d_bx3(const void* x, const void* w_packed, const float* scale, const fl
     a.relu = relu;
     a.y_f32 = 1;
     a.vec_epi = 0;
+    a.epi_prio = 0;
     a.rH = 0; a.rW = 0;
     a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
     set_row_split(a);
