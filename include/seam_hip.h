@@ -416,6 +416,26 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
                             seam_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * The match trunk as one call (SURVEY.md 8b `seam_match_trunk_f32`): MatchPredictor / TemporalAggregationNLB's
+ * conv_seq (4 valid 3x3 convs + ReLU, 14 -> 12 -> 10 -> 8 -> 6) -> AvgPool2d(6,6) + ReLU -> Linear(1024,256) + BatchNorm1d
+ * (ref models/match_head.py:50-62,67-69,93-95).  roi NHWC [K,14,14,256] -> x3 [K,256].  Six launches on `stream` (why the
+ * kernels are not fused further: csrc/seam_trunk.hip).  conv[4] / linear: the packed weights of the layers -- `w` from
+ * seam_pack_conv_weight_f32 (required for `linear`; for a conv it may be NULL when a Winograd form is given), `u` / `u24` from
+ * seam_pack_conv_weight_wino_f32 / _wino24_f32 or NULL, `scale` / `shift` the [K] epilogue vectors (bias; for `linear` the folded
+ * BatchNorm1d) or NULL.  form: int[4] per conv -- 0 implicit GEMM, 1 F(2x2,3x3), 2 F(2x4,3x3) -- or NULL: chosen on the map
+ * geometry as the Python layer does.  ws: >= seam_match_trunk_workspace_floats(K) floats. */
+typedef struct {
+    const float* w;
+    const float* u;
+    const float* u24;
+    const float* scale;
+    const float* shift;
+} seam_trunk_layer_t;
+int64_t seam_match_trunk_workspace_floats(int K);
+int seam_match_trunk_f32(const float* roi, const seam_trunk_layer_t* conv, const seam_trunk_layer_t* linear, float* x3,
+                         int K, float* ws, const int* form, seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Gradient kernels of the match heads: the grad-enabled pass of the training loop,
  * stuffs/engine.py:120-121,158-168,183-185 -> MatchPredictor / TemporalAggregationNLB in .train()
  * (models/match_head.py:66-76,90-169,339).  fp32, fixed-order reductions (bit-reproducible).

@@ -22,6 +22,11 @@ _i = C.c_int
 _f = C.c_float
 _i64 = C.c_int64
 
+class TrunkLayer(C.Structure):
+    """seam_trunk_layer_t of include/seam_hip.h."""
+    _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("u24", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/seam_hip.h one to one
 SIGNATURES = {
     "seam_version": (_i, []),
@@ -90,6 +95,8 @@ SIGNATURES = {
     "seam_box_iou_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_pair_topk_workspace_floats": (_i64, [_i, _i, _i]),
     "seam_pair_topk_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "seam_match_trunk_workspace_floats": (_i64, [_i]),
+    "seam_match_trunk_f32": (_i, [_p, C.POINTER(TrunkLayer), C.POINTER(TrunkLayer), _p, _i, _p, C.POINTER(_i), _p]),
     "seam_pair_topk_mfma_min_gallery": (_i, []),
     "seam_pair_topk_mfma_max_k": (_i, []),
     "seam_pair_topk_mfma_workspace_floats": (_i64, [_i, _i, _i]),

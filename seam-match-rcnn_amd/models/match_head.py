@@ -133,6 +133,9 @@ class MatchPredictor(nn.Module):
         if x.shape[0] == 0:
             return torch.empty((0, 256), dtype=torch.float32, device=x.device)
         convs, lin = self._packed_trunk()
+        if (x.dtype == torch.float32 and ops.CONV_TRACE is None and tuple(x.shape[1:]) == (14, 14, 256)
+                and all(pc.dtype == torch.float32 for pc in convs)):
+            return ops.match_trunk(x, convs, lin)     # one ABI call (seam_match_trunk_f32): the same six launches
         for pc in convs:                       # 14 -> 12 -> 10 -> 8 -> 6, ReLU fused
             x = ops.conv2d(x, pc, relu=True)
         x = ops.avgpool(x)                     # AvgPool2d(6,6); the following ReLU is a no-op (x >= 0)

@@ -513,6 +513,32 @@ def linear(x: torch.Tensor, pc: PackedConv, relu: bool = False, out_f32: bool = 
     return conv2d(x.view(m, 1, 1, c), pc, relu, out_f32=out_f32).view(m, pc.K)
 
 
+def match_trunk(x: torch.Tensor, convs: Sequence[PackedConv], lin: PackedConv) -> torch.Tensor:
+    """The match trunk in ONE ABI call (seam_match_trunk_f32): x NHWC fp32 [K,14,14,256], the four packed 3x3 convs and the packed
+    Linear + BatchNorm1d -> x3 [K,256].  The form of every conv is decided here, by the rule ``conv2d`` applies (so the Python
+    knobs SEAM_WINOGRAD / SEAM_WINOGRAD24 / SEAM_WINO_MIN_FILL act on both paths alike) and handed down."""
+    lib = _native.lib()
+    x = _req(x, F32, "x")
+    k = x.shape[0]
+    if tuple(x.shape[1:]) != (14, 14, 256) or len(convs) != 4 or any(pc.dtype != F32 for pc in list(convs) + [lin]):
+        raise ValueError("match_trunk: fp32 NHWC [K,14,14,256] input and fp32-packed layers expected")
+    out = torch.empty((k, 256), dtype=F32, device=x.device)
+    if k == 0:
+        return out
+
+    def layer(pc):
+        return _native.TrunkLayer(*(None if t is None else t.data_ptr() for t in (pc.w, pc.u, pc.u24, pc.scale, pc.shift)))
+    layers = (_native.TrunkLayer * 4)(*[layer(pc) for pc in convs])
+    form = (C.c_int * 4)()
+    for i, (pc, h) in enumerate(zip(convs, (14, 12, 10, 8))):
+        wino = pc.u is not None and WINOGRAD and _wino_pays(lib, k, h, h, 256, pc.K, 0)
+        form[i] = 2 if (wino and pc.u24 is not None and WINOGRAD24 and _wino24_pays(lib, k, h, h, 256, pc.K, 0)) else (1 if wino else 0)
+    ws = torch.empty((int(lib.seam_match_trunk_workspace_floats(k)),), dtype=F32, device=x.device)
+    _native.check(lib.seam_match_trunk_f32(_ptr(x), layers, C.byref(layer(lin)), _ptr(out), k, _ptr(ws), form, _stream()),
+                  "seam_match_trunk_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------ elementwise
 def _sfx(dtype) -> str:
     return "f32" if dtype == F32 else "f16"

@@ -315,6 +315,41 @@ def test_roi_align_lds_tiles_equal_the_gather_kernel(ops, dtype):
         lib.seam_roi_align_set_lds(0)
 
 
+def test_match_trunk_one_call_equals_the_launch_sequence(ops):
+    """seam_match_trunk_f32: bit-identical to conv x4 + avg-pool + Linear/BN issued one by one, with the form of every
+    conv chosen by the library (form = NULL) or handed down; and against the oracle's trunk."""
+    import ctypes as C
+    from seam_match_rcnn_amd import _native
+    from seam_match_rcnn_amd.models.match_head import MatchPredictor
+    d = dev()
+    p = to_torch(synth.match_predictor_state(11))
+    mp = MatchPredictor()
+    mp.load_state_dict(p)
+    mp = mp.to(d).eval()
+    x = torch.from_numpy(synth.roi_features(61, 37))
+    xn = nhwc(x).to(d)
+    convs, lin = mp._packed_trunk()
+    with torch.no_grad():
+        y = xn
+        for pc in convs:
+            y = ops.conv2d(y, pc, relu=True)
+        ref = ops.linear(ops.avgpool(y), lin, out_f32=True)
+        one = ops.match_trunk(xn, convs, lin)
+        via_module = mp.trunk_nhwc(xn)
+    assert torch.equal(one, ref) and torch.equal(via_module, ref)
+    assert_close(one, OH.match_trunk(x, p))
+    # form = NULL: the C side picks the forms itself -- the same ones
+    lib = _native.lib()
+    layer = lambda pc: _native.TrunkLayer(*(None if t is None else t.data_ptr() for t in (pc.w, pc.u, pc.u24, pc.scale, pc.shift)))
+    layers = (_native.TrunkLayer * 4)(*[layer(pc) for pc in convs])
+    out = torch.empty((37, 256), device=d)
+    ws = torch.empty((int(lib.seam_match_trunk_workspace_floats(37)),), device=d)
+    rc = lib.seam_match_trunk_f32(xn.data_ptr(), layers, C.byref(layer(lin)), out.data_ptr(), 37, ws.data_ptr(), None,
+                                  torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and torch.equal(out, ref)
+    assert ops.match_trunk(xn[:0], convs, lin).shape == (0, 256)
+
+
 def test_nlb_attnpool_golden_and_oracle(ops, golden):
     d = dev()
     from seam_match_rcnn_amd.models.match_head import pack_nlb_from_state
