@@ -12,14 +12,15 @@
 //
 //   1. pairmf_prep        awm2[q] = -2 wd o a_q, A_q, and P_q = sum_k (|W0_k| + |W1_k|) a_qk^2 (for the error bound)
 //   2. pairmf_kernel<1>   d' of all queries against 4096 bank rows sampled in 16-row groups across the bank -> dense [Q,4096]
-//   3. pairmf_thresh      tau_q = kk-th largest sampled d' (kk = k + margin): a lower bound of the final kk-th largest
+//   3. pairmf_thresh      tau_q = kk-th largest sampled d' (kk = k + margin): a lower bound of the final kk-th largest (two-level
+//                         radix select: every wave keeps the kk largest of its quarter, wave 0 selects among the 4 kk survivors)
 //   4. pairmf_kernel<0>   the whole bank: every (q, j) with d' >= tau_q is a candidate (about G * kk / 4096 per query; nothing
-//                         else reaches HBM).  A wave parks its finds in LDS and writes them, at the end, to ITS OWN region
-//                         [query group of 32][block] -- no atomics: 250 blocks appending to 256 per-query lists through
-//                         same-address L2 atomics cost 16 us of serialisation (measured); only a wave whose region is full
-//                         falls back to the atomic per-query overflow lists.
-//   5. pairmf_final       per query: gathers its candidates from its group's regions (+ overflow list) into LDS, takes the kk
-//                         best by d', re-scores them exactly, orders them, writes the top k; the bound check.
+//                         else reaches HBM).  A wave parks its finds in LDS and writes them, at the end, into the slots of
+//                         (query, this block) -- no global atomics: 250 blocks appending to 256 per-query lists through
+//                         same-address L2 atomics cost 16 us of serialisation (measured); only a (query, block) pair whose
+//                         slots are full falls back to the atomic per-query overflow lists.
+//   5. pairmf_final       per query: gathers its candidates from its slots of every block (+ overflow list) into LDS, takes
+//                         the kk best by d', re-scores them exactly, orders them, writes the top k; the bound check.
 //
 // pairmf_kernel -- the GEMM -- is built for CDNA4's exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 32 cycles per issue):
 //   * 512 threads = 8 waves (2 per SIMD, both MFMA-bound, so they alternate on the matrix pipe); each wave OWNS 32 queries
@@ -30,7 +31,8 @@
 //     ds_read_b128, one per 8 MFMAs); the bank streams from HBM exactly once (2 B / clk / CU -- far from any limit).
 //   * k is consumed in the order k = 64 h + 4 u + e (h = lane >> 4 the MFMA's k sub-index, u the 16-byte slot, e the element),
 //     the same permutation on both operands; a tile may end in a 16-row group, so a bank of G rows costs ceil(G/256/16) row
-//     groups per CU -- 80 rows for G = 20 000, 2.4 % padding.
+//     groups per CU -- 80 rows for G = 20 000, 2.4 % padding.  (The fp32 MFMA shares the SIMD's FMA lanes with the VALU: 16 MFMAs
+//     per ds_read_b128 pair keeps the non-MFMA share of the loop near 6 %.)
 //   * epilogue on the VALU beside the other wave's MFMAs: d' = acc + A_q + B_j, compare with tau_q, ballot + prefix count into LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -345,9 +347,8 @@ __global__ __launch_bounds__(256) void pairmf_thresh(const float* __restrict__ d
 #pragma unroll
         for (int e = 0; e < 4; ++e) key[4 * i + e] = tk_key_d(v[e]);
     }
-    unsigned* hist = sh.hist + 0;                   // 256 words per wave: hist / key / item / gidx of TopkShared, one each
+    // 256 histogram words per wave: the hist / key / item / gidx arrays of TopkShared, one each
     unsigned* myhist = wid == 0 ? sh.hist : wid == 1 ? sh.key : wid == 2 ? reinterpret_cast<unsigned*>(sh.item) : reinterpret_cast<unsigned*>(sh.gidx);
-    (void)hist;
     unsigned krem;
     const unsigned T = wave_kth<PER>(key, NS_ROWS / 4, kk, myhist, krem);
     // survivors: every key above T, then krem copies of T (only the VALUES matter for a threshold)
