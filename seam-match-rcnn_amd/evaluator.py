@@ -162,6 +162,50 @@ class RetrievalReport:
         """(ret1, ret2, ret3) as ``evaluate`` returns them (:341,350,355,445)."""
         return (float(self.accuracy("frame")[0]), float(self.accuracy("avg_desc")[0]), float(self.accuracy("aggr_desc")[0]))
 
+    # ---- what the reference prints and writes at the end of evaluate() (:336-443) ---------------------------------------
+    _TITLES = (("frame", ""), ("max_per_image", " Product Max"), ("avg_desc", " Product Avg Desc"), ("aggr_desc", " Product Aggr Desc"),
+               ("avg_dist", " Product Avg Dist"), ("max_dist", " Product Max Dist"), ("max_score", " Product Max Score"))
+
+    def tables_text(self) -> str:
+        """The accuracy tables exactly as the reference prints them: all products, then "Regular ONLY", then "Hard ONLY"
+        (those two without the "Product Max" table, which the reference keeps for all products only), the rank quartiles and the
+        average track length.  (A subset without products prints nan where the reference raises ZeroDivisionError.)"""
+        lines = []
+        for sub, head in (("", None), ("_reg", "\n\n\n Regular ONLY"), ("_hard", "\n\n\n Hard ONLY")):
+            if head is not None:
+                lines.append(head)
+            n = {"": self.count_street, "_reg": self.count_reg, "_hard": self.count_hard}[sub]
+            for name, title in self._TITLES:
+                if sub and name == "max_per_image":
+                    continue
+                denom = n * self.frames_per_product if name == "frame" else n
+                for k, hits in zip(self.k_thresholds, self.counts[name + sub]):
+                    lines.append("Top-%d Retrieval Accuracy%s: %1.4f" % (k, title, int(hits) / denom if denom else float("nan")))
+                lines.append("*" * 50)
+        ranks = np.asarray(self.frame_ranks)
+        lines.append(f"Rank median: {np.median(ranks)}; rank 1st quartile: {np.percentile(ranks, 25)}; "
+                     f"rank 3rd quartile: {np.percentile(ranks, 75)}")
+        lines.append(f"Average Track Length: {float(np.asarray(self.track_lens).mean())}")
+        return "\n".join(lines) + "\n"
+
+    def perf_rows(self) -> np.ndarray:
+        """The 8 x len(k) block the reference writes to logs_mf/<time>.csv (:439-443): rows 0-3 = per-frame, product-max,
+        avg-desc and aggr-desc accuracies in percent, rows 4-7 zero."""
+        perf = np.zeros((8, len(self.k_thresholds)))
+        tq = self.count_street * self.frames_per_product
+        perf[0] = np.asarray(self.counts["frame"], dtype=np.float32) / tq
+        for row, name in ((1, "max_per_image"), (2, "avg_desc"), (3, "aggr_desc")):
+            perf[row] = np.asarray(self.counts[name], dtype=np.float32) / self.count_street
+        return perf * 100
+
+    def save_artifacts(self, directory: str = ".") -> None:
+        """The files the reference leaves behind: ``accs_per_product.pth`` (:336) and ``logs_mf/<time>.csv`` (:441-443)."""
+        import os
+        import time
+        torch.save(self.per_product, os.path.join(directory, "accs_per_product.pth"))
+        os.makedirs(os.path.join(directory, "logs_mf"), exist_ok=True)
+        np.savetxt(os.path.join(directory, "logs_mf", str(time.time()) + ".csv"), self.perf_rows(), fmt="%02.2f", delimiter="\t")
+
 
 _TABLES = ("frame", "max_per_image", "aggr_desc", "avg_desc", "avg_dist", "max_dist", "max_score")
 
@@ -255,12 +299,18 @@ def evaluate_tables(t: DescriptorTables, temporal_aggregator, k_thresholds: Sequ
 @torch.no_grad()
 def evaluate(model, data_loader, device, score_threshold: float = 0.0, k_thresholds: Sequence[int] = K_THRESHOLDS,
              frames_per_product: int = 3, tracking_threshold: float = 0.3, first_n_withvideo: Optional[int] = None,
-             return_report: bool = False):
+             return_report: bool = False, verbose: bool = True, artifacts_dir: Optional[str] = None):
     """Same signature and return value (ret1, ret2, ret3) as the reference's ``evaluate``
-    (evaluate_movingfashion.py:15-16,445)."""
+    (evaluate_movingfashion.py:15-16,445).  ``verbose`` prints the accuracy tables as the reference does (:338-437);
+    ``artifacts_dir`` (e.g. ".") also writes ``accs_per_product.pth`` and ``logs_mf/<time>.csv`` there (:336,441-443) -- the
+    reference always writes them into the working directory; here that is opt-in."""
     tables = collect_descriptors(model, data_loader, device, score_threshold, first_n_withvideo)
     ids = getattr(getattr(data_loader, "dataset", None), "product_ids", None)
     if ids is not None:                     # the reference keys accs_per_product by dataset.product_ids[targets[0]["i"]] (:160)
         tables.product_keys = [ids[i] for i in tables.product_keys]
     rep = evaluate_tables(tables, model.roi_heads.temporal_aggregator, k_thresholds, frames_per_product, tracking_threshold)
+    if verbose:
+        print(rep.tables_text(), end="")
+    if artifacts_dir is not None:
+        rep.save_artifacts(artifacts_dir)
     return (rep.summary(), rep) if return_report else rep.summary()

@@ -13,8 +13,9 @@ the reference's ``TemporalAggregationNLB`` with the repo's synthetic weights.  T
 outputs (tests/eval_scenarios.py) -- the part under test is everything after it: descriptor collection, fp16 tables, tracklet
 linking, the seven rankings, the counters.
 
-What is stored (outputs only, no reference text): for each scenario the 21 hit-counter vectors, count_reg / count_hard /
-count_street, track_lens, all_ranks_list, (ret1, ret2, ret3), accs_per_product, and the descriptor tables the reference built
+What is stored (outputs only, no reference source text): for each scenario the 21 hit-counter vectors, count_reg / count_hard /
+count_street, track_lens, all_ranks_list, (ret1, ret2, ret3), accs_per_product, what it printed (the accuracy tables), the
+`logs_mf/*.csv` row block it wrote, and the descriptor tables the reference built
 (shop / street aggregator descriptors as it stored them, fp16) -- read out of ``evaluate``'s frame when it returns
 (``sys.setprofile``), since the function itself only prints and returns three numbers.
 
@@ -106,7 +107,9 @@ def run_reference(EM, agg, name):
             sys.setprofile(None)
             os.chdir(cwd)
         per_product = torch.load(os.path.join(tmp, "accs_per_product.pth"), weights_only=False)
-    g = {"ret": np.asarray(ret, np.float64)}
+        csvs = sorted(os.listdir(os.path.join(tmp, "logs_mf")))
+        csv_text = open(os.path.join(tmp, "logs_mf", csvs[0])).read()
+    g = {"ret": np.asarray(ret, np.float64), "perf_csv": np.asarray(csv_text)}
     for k in COUNTERS:
         g[k] = np.asarray(grabbed[k], np.int64)
     for k in SCALARS:
@@ -162,6 +165,7 @@ def main():
         print(f"  smallest score of a true product: {least_score:.3e}")
         assert worst > 5e-3, f"scenario {name} is not decided under fp16: least margin {worst}"
         assert least_score > 1e-6, f"scenario {name}: a true product's score ({least_score}) is not representable in fp16"
+        g["stdout"] = np.asarray(text)              # every line evaluate() printed (the accuracy tables), verbatim
         for k, v in g.items():
             store[f"{name}_{k}"] = v
     path = os.path.join(HERE, "eval_golden.npz")

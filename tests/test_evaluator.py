@@ -63,6 +63,16 @@ def test_oracle_matches_reference_evaluate(name, eval_golden):
     fpp, cs = params["frames_per_product"], tab["count_street"]
     ret = (out["frame"][0] / (cs * fpp), out["avg_desc"][0] / cs, out["aggr_desc"][0] / cs)
     np.testing.assert_allclose(ret, g[f"{name}_ret"], rtol=0, atol=1e-12)
+    # what the drop-in evaluate() prints and writes, from these counters == what the reference printed and wrote
+    from seam_match_rcnn_amd.evaluator import RetrievalReport
+    rep = RetrievalReport(k_thresholds=(1, 5, 10, 20), count_street=cs, count_reg=out["count_reg"], count_hard=out["count_hard"],
+                          frames_per_product=fpp, track_lens=out["track_lens"], frame_ranks=out["frame_ranks"],
+                          counts={k: v for k, v in out.items() if isinstance(v, np.ndarray)})
+    assert rep.tables_text() == str(g[f"{name}_stdout"])
+    import io
+    buf = io.StringIO()
+    np.savetxt(buf, rep.perf_rows(), fmt="%02.2f", delimiter="\t")
+    assert buf.getvalue() == str(g[f"{name}_perf_csv"])
 
 
 @pytest.mark.gpu
@@ -79,7 +89,17 @@ def test_device_evaluate_matches_reference_evaluate(name, eval_golden):
     ta = TemporalAggregationNLB()
     ta.load_state_dict(to_torch(ES.aggregator_state()))
     ta = ta.to(dev).eval()
-    ret, rep = EV.evaluate(ES.CannedModel(canned, ta), loader, dev, return_report=True, **params)
+    import contextlib
+    import io
+    import os
+    import tempfile
+    buf = io.StringIO()
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(buf):
+        ret, rep = EV.evaluate(ES.CannedModel(canned, ta), loader, dev, return_report=True, artifacts_dir=tmp, **params)
+        saved = torch.load(os.path.join(tmp, "accs_per_product.pth"), weights_only=False)
+        csv = open(os.path.join(tmp, "logs_mf", os.listdir(os.path.join(tmp, "logs_mf"))[0])).read()
+    assert buf.getvalue() == str(g[f"{name}_stdout"]) and csv == str(g[f"{name}_perf_csv"])      # printed tables, CSV: verbatim
+    assert [str(k) for k in saved] == g[f"{name}_per_product_keys"].tolist()
     _check_counters(lambda t, s: rep.counts[t + s], rep.track_lens, rep.frame_ranks, (rep.count_reg, rep.count_hard, rep.count_street),
                     g, name)
     np.testing.assert_allclose(ret, g[f"{name}_ret"], rtol=0, atol=1e-12)
