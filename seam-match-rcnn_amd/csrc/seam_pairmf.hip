@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void pairmf_kernel(const MfArgs p) {
     __shared__ float wdl[D], awl[D];
     __shared__ float rred[8];
     // candidates a wave finds are parked here (ballot + prefix count, no atomics, no memory round trip beside the MFMAs) and go
-    // to the per-query lists in one burst of fire-and-forget atomics: (d', bank row, query)
+    // to the slots of (query, this block) when the block's rows are done: (d', bank row, query)
     __shared__ float wb_v[SAMPLE ? 1 : 8][SAMPLE ? 1 : WCAP];
     __shared__ int wb_g[SAMPLE ? 1 : 8][SAMPLE ? 1 : WCAP];
     __shared__ int wb_q[SAMPLE ? 1 : 8][SAMPLE ? 1 : WCAP];
