@@ -1,23 +1,27 @@
 // seam_roialign.hip -- MultiScaleRoIAlign + roi_align(aligned=False) on NHWC pyramids (gfx950).
 //
-// Two kernels, bit-identical results (the same expression per sample, in the same order):
+// Three kernels, bit-identical results (the same expression per sample, in the same order); A/B in profiles/r03_roialign_ab.txt:
 //
+// roi_align_quad_kernel (default) LDS-staged ROI tiles (what BASELINE.json's north_star names): one block per (ROI quadrant of 7 x 7
+//                       bins, 64-channel quarter).  The quadrant's whole footprint (<= 16 x 16 feature pixels x 256 B = 64 KB) is
+//                       read once, as coalesced 256-byte pixel segments, every thread's loads in flight together; while they fly the
+//                       bilinear taps of the quadrant's 196 samples (4 weights + 4 LDS offsets) are computed ONCE per block -- the
+//                       coordinate arithmetic, ~40 VALU instructions per sample, is what bounds this operator; ONE barrier; then
+//                       49 bins x 16 channel groups come from LDS (conflict-free ds_read_b128: the 16 lanes of a read group hold the
+//                       16 channel groups).  sampling_ratio 2, P <= 16, C % 64 == 0; a footprint larger than the window takes the
+//                       gather path inside the same kernel.
 // roi_align_kernel      one wave64 per output bin: lane l owns channels [4l,4l+4) (+256 per extra pass), so each of the
 //                       16 bilinear taps of a bin is ONE coalesced 1 KiB wave load (channels are contiguous in NHWC);
-//                       neighbouring bins/ROIs re-hit the taps in L1/L2.  Sample coordinates are wave-uniform.
-//                       Gather-bound: 0.80 M tap loads per 14x14 ROI vs 200 704 B written.
-// roi_align_lds_kernel  LDS-staged ROI tiles (what BASELINE.json's north_star names): one block per (ROI, 64-channel quarter);
-//                       for every row of bins the (at most four) feature rows its two sample rows touch are read ONCE, as
-//                       contiguous row segments (ROI width x 256 B), into LDS through a register-staged prefetch that runs one
-//                       bin row ahead; the 14 bins x 16 taps then come from LDS (conflict-free ds_read_b128: the 16 lanes of a
-//                       read group hold the 16 channel groups).  L2 -> CU traffic per ROI drops from 16 taps x 196 bins x 1 KiB
-//                       = 3.2 MB to about 1.3 x the ROI's footprint.  sampling_ratio 2, P <= 16, C % 64 == 0; ROIs wider than
-//                       40 feature pixels take the gather path inside the same kernel.
+//                       neighbouring bins/ROIs re-hit the taps in L1/L2; every lane repeats the sample arithmetic.  The general form
+//                       (any sampling_ratio / P / C % 4 == 0).
+// roi_align_lds_kernel  row-staged tiles: per row of bins the <= 4 feature rows its two sample rows touch go through LDS with a
+//                       register-staged prefetch one bin row ahead.  Kept for the A/B: latency-bound (14 dependent stages), slower.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -238,11 +242,156 @@ __global__ __launch_bounds__(256) void roi_align_lds_kernel(const RoiArgs p) {
     }
 }
 
-int g_roi_lds = -1;              // -1: read SEAM_ROIALIGN_LDS on first use (default OFF: the gather kernel measured faster, profiles/r03_roialign_ab.txt)
+// ---- second staged form: one block per (ROI quadrant of bins, 64-channel quarter).  The quadrant's WHOLE footprint (<= 16 x 16
+// feature pixels x 256 B = 64 KB) is fetched at once -- every thread's loads in flight together -- then ONE barrier, then the <= 49
+// bins x 16 channel groups come from LDS.  No chain of dependent stages; a footprint that does not fit takes the gather path.
+constexpr int RQ_PX = 16;        // footprint rows / columns that fit
+
+template <typename T, int CB>
+__global__ __launch_bounds__(256) void roi_align_quad_kernel(const RoiArgs p) {
+    constexpr int LPC = CB / 4;                 // lanes per pixel (a lane owns 4 channels)
+    constexpr int RPP = 256 / LPC / RQ_PX;      // footprint rows one staging pass of the block covers (1 at 64 channels, 2 at 32)
+    constexpr int NST = RQ_PX / RPP;
+    typedef T tv4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) T fp[RQ_PX][RQ_PX][CB];
+    __shared__ __attribute__((aligned(16))) f32x4 s_w[256];          // per sample of the quadrant: the four bilinear weights ...
+    __shared__ __attribute__((aligned(16))) i32x4 s_o[256];          // ... and the four tap offsets into fp (elements; < 0: sample outside)
+    const int tid = threadIdx.x, cg = tid & (LPC - 1);
+    const int nq = p.C / CB;
+    const int quad = blockIdx.x & 3, rest = blockIdx.x >> 2;
+    const int k = rest / nq, cq = rest - k * nq;
+    const int hp = (p.P + 1) >> 1;                                   // bins per quadrant side (7 of 14; 4 + 3 of 7)
+    const int ph0 = (quad >> 1) * hp, ph1 = min(p.P, ph0 + hp), pw0 = (quad & 1) * hp, pw1 = min(p.P, pw0 + hp);
+    const int nbh = ph1 - ph0, nbw = pw1 - pw0;
+
+    const float* r = p.rois + (size_t)k * 5;
+    const int bidx = (int)r[0];
+    const float bx1 = r[1], by1 = r[2], bx2 = r[3], by2 = r[4];
+    const int lvl = p.levels ? p.levels[k] : map_level(bx1, by1, bx2, by2, p.k_min);
+    const int H = lvl == 0 ? p.h[0] : lvl == 1 ? p.h[1] : lvl == 2 ? p.h[2] : p.h[3];
+    const int W = lvl == 0 ? p.w[0] : lvl == 1 ? p.w[1] : lvl == 2 ? p.w[2] : p.w[3];
+    const float sc = lvl == 0 ? p.scale[0] : lvl == 1 ? p.scale[1] : lvl == 2 ? p.scale[2] : p.scale[3];
+    const T* fb = (const T*)(lvl == 0 ? p.feat[0] : lvl == 1 ? p.feat[1] : lvl == 2 ? p.feat[2] : p.feat[3]);
+    const T* f = fb + (size_t)bidx * H * W * p.C + cq * CB;
+
+    const float x1 = bx1 * sc, y1 = by1 * sc, x2 = bx2 * sc, y2 = by2 * sc;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    const float bw = rw / (float)p.P, bh = rh / (float)p.P;
+
+    auto tap = [&](float v, int lim, int& lo, int& hi, float& vv) {      // the gather kernel's clamping of one coordinate
+        vv = fmaxf(v, 0.f);
+        lo = (int)vv;
+        if (lo >= lim - 1) { lo = hi = lim - 1; vv = (float)lo; } else { hi = lo + 1; }
+    };
+    auto sx = [&](int pw, int ix) { return x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / 2.f; };
+    auto sy = [&](int ph, int iy) { return y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / 2.f; };
+    int xlo, xhi, ylo, yhi;
+    {
+        float t;
+        int a;
+        tap(sx(pw0, 0), W, xlo, a, t);
+        tap(sx(pw1 - 1, 1), W, a, xhi, t);
+        tap(sy(ph0, 0), H, ylo, a, t);
+        tap(sy(ph1 - 1, 1), H, a, yhi, t);
+    }
+    const int wpx = xhi - xlo + 1, hpx = yhi - ylo + 1;
+    const bool staged = wpx <= RQ_PX && hpx <= RQ_PX;               // block-uniform
+    if (staged) {
+        // thread -> (row phase, pixel column, channel group): one 16-byte vector per RPP footprint rows, all requested before any is stored
+        const int px = (tid / LPC) % RQ_PX, pr = tid / (LPC * RQ_PX);
+        tv4 st[NST];
+        const bool col_ok = px < wpx;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int py = i * RPP + pr;
+            const int yy = min(ylo + py, yhi), xx = min(xlo + px, xhi);
+            // rows and columns past the footprint issue no memory request
+            if (py < hpx && col_ok) st[i] = *reinterpret_cast<const tv4*>(f + ((size_t)yy * W + xx) * p.C + cg * 4);
+        }
+        // while the loads fly: the bilinear taps of every sample of the quadrant, ONCE per block (196 records for 7 x 7 bins) instead of
+        // once per channel-group lane -- the coordinate arithmetic is what bounds this operator (about 40 VALU instructions per sample,
+        // repeated by the 64 channel lanes of a bin in the gather kernel)
+        if (tid < 4 * nbh * nbw) {
+            const int bin = tid >> 2, iy = (tid >> 1) & 1, ix = tid & 1;
+            const int bh_i = bin / nbw, ph = ph0 + bh_i, pw = pw0 + (bin - bh_i * nbw);
+            const float y = sy(ph, iy);
+            float x = sx(pw, ix);
+            const bool ok = !(y < -1.f || y > (float)H || x < -1.f || x > (float)W);
+            int yl, yh, xl, xh;
+            float yy;
+            tap(y, H, yl, yh, yy);
+            tap(x, W, xl, xh, x);
+            const float ly = yy - (float)yl, lx = x - (float)xl;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            s_w[tid] = f32x4{hy * hx, hy * lx, ly * hx, ly * lx};
+            const int r0 = (yl - ylo) * RQ_PX, r1 = (yh - ylo) * RQ_PX, c0 = xl - xlo, c1 = xh - xlo;
+            s_o[tid] = ok ? i32x4{(r0 + c0) * CB, (r0 + c1) * CB, (r1 + c0) * CB, (r1 + c1) * CB} : i32x4{-1, -1, -1, -1};
+        }
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (i * RPP + pr < hpx && col_ok) *reinterpret_cast<tv4*>(&fp[i * RPP + pr][px][cg * 4]) = st[i];
+        __syncthreads();
+        const T* base = &fp[0][0][cg * 4];
+        for (int t = tid / LPC; t < nbh * nbw; t += 256 / LPC) {
+            const int bh_i = t / nbw, ph = ph0 + bh_i, pw = pw0 + (t - bh_i * nbw);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int smp = 0; smp < 4; ++smp) {                     // (iy, ix) = (0,0) (0,1) (1,0) (1,1): the gather kernel's order
+                const i32x4 o = s_o[4 * t + smp];
+                if (o[0] < 0) continue;
+                const f32x4 w = s_w[4 * t + smp];
+                const f32x4 v1 = __builtin_convertvector(*reinterpret_cast<const tv4*>(base + o[0]), f32x4);
+                const f32x4 v2 = __builtin_convertvector(*reinterpret_cast<const tv4*>(base + o[1]), f32x4);
+                const f32x4 v3 = __builtin_convertvector(*reinterpret_cast<const tv4*>(base + o[2]), f32x4);
+                const f32x4 v4 = __builtin_convertvector(*reinterpret_cast<const tv4*>(base + o[3]), f32x4);
+                acc = sample_acc(acc, w[0], v1, w[1], v2, w[2], v3, w[3], v4);
+            }
+            acc /= 4.f;
+            *reinterpret_cast<tv4*>((T*)p.out + ((size_t)k * p.P * p.P + (size_t)ph * p.P + pw) * p.C + cq * CB + cg * 4) =
+                __builtin_convertvector(acc, tv4);
+        }
+        return;
+    }
+    // footprint larger than the LDS window: every lane gathers its taps from L1 / L2, as roi_align_kernel does
+    for (int t = tid / LPC; t < nbh * nbw; t += 256 / LPC) {
+        const int bh_i = t / nbw, ph = ph0 + bh_i, pw = pw0 + (t - bh_i * nbw);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy) {
+            const float y = sy(ph, iy);
+            const bool yok = !(y < -1.f || y > (float)H);
+            int yl, yh;
+            float yy;
+            tap(y, H, yl, yh, yy);
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                float x = sx(pw, ix);
+                if (!yok || x < -1.f || x > (float)W) continue;
+                int xl, xh;
+                tap(x, W, xl, xh, x);
+                const float ly = yy - (float)yl, lx = x - (float)xl;
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                const tv4 t1 = *reinterpret_cast<const tv4*>(f + ((size_t)yl * W + xl) * p.C + cg * 4);
+                const tv4 t2 = *reinterpret_cast<const tv4*>(f + ((size_t)yl * W + xh) * p.C + cg * 4);
+                const tv4 t3 = *reinterpret_cast<const tv4*>(f + ((size_t)yh * W + xl) * p.C + cg * 4);
+                const tv4 t4 = *reinterpret_cast<const tv4*>(f + ((size_t)yh * W + xh) * p.C + cg * 4);
+                const f32x4 v1 = __builtin_convertvector(t1, f32x4), v2 = __builtin_convertvector(t2, f32x4);
+                const f32x4 v3 = __builtin_convertvector(t3, f32x4), v4 = __builtin_convertvector(t4, f32x4);
+                acc = sample_acc(acc, w1, v1, w2, v2, w3, v3, w4, v4);
+            }
+        }
+        acc /= 4.f;
+        *reinterpret_cast<tv4*>((T*)p.out + ((size_t)k * p.P * p.P + (size_t)ph * p.P + pw) * p.C + cq * CB + cg * 4) =
+            __builtin_convertvector(acc, tv4);
+    }
+}
+
+int g_roi_lds = -1;              // -1: read SEAM_ROIALIGN_LDS on first use: 0 gather, 1 row-staged tiles, 2 (default) quadrant tiles -- profiles/r03_roialign_ab.txt
 
 }  // namespace
 
-extern "C" void seam_roi_align_set_lds(int on) { g_roi_lds = on ? 1 : 0; }
+extern "C" void seam_roi_align_set_lds(int on) { g_roi_lds = on < 0 ? 0 : on > 2 ? 2 : on; }
 
 template <typename T>
 static int roi_align_launch(const void* feat0, const void* feat1, const void* feat2, const void* feat3, const int* hw, int C,
@@ -258,9 +407,14 @@ static int roi_align_launch(const void* feat0, const void* feat1, const void* fe
     a.sr = sampling_ratio;
     if (g_roi_lds < 0) {
         const char* e = getenv("SEAM_ROIALIGN_LDS");
-        g_roi_lds = (e && e[0] == '1') ? 1 : 0;
+        g_roi_lds = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : 2;
     }
-    if (g_roi_lds && sampling_ratio == 2 && P <= 16 && (C % RA_CB) == 0) {
+    if (g_roi_lds == 2 && sampling_ratio == 2 && P <= 16 && (C % RA_CB) == 0) {
+        // (64 channels per block; 32 -- more blocks per CU -- measured 2.2x slower in fp32: 128-byte pixel rows alias in LDS)
+        hipLaunchKernelGGL((roi_align_quad_kernel<T, RA_CB>), dim3((unsigned)((long)K * (C / RA_CB) * 4)), dim3(256), 0, (hipStream_t)stream, a);
+        return (int)hipGetLastError();
+    }
+    if (g_roi_lds == 1 && sampling_ratio == 2 && P <= 16 && (C % RA_CB) == 0) {
         hipLaunchKernelGGL(roi_align_lds_kernel<T>, dim3((unsigned)((long)K * (C / RA_CB))), dim3(256), 0, (hipStream_t)stream, a);
         return (int)hipGetLastError();
     }

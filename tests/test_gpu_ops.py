@@ -308,11 +308,12 @@ def test_roi_align_lds_tiles_equal_the_gather_kernel(ops, dtype):
         for pooled in (14, 7):
             lib.seam_roi_align_set_lds(0)
             ref = ops.roi_align(feats, rois, scales, pooled)
-            lib.seam_roi_align_set_lds(1)
-            out = ops.roi_align(feats, rois, scales, pooled)
-            assert torch.equal(out, ref), (pooled, float((out.float() - ref.float()).abs().max()))
+            for mode in (1, 2):                     # row-staged tiles, whole-quadrant tiles
+                lib.seam_roi_align_set_lds(mode)
+                out = ops.roi_align(feats, rois, scales, pooled)
+                assert torch.equal(out, ref), (mode, pooled, float((out.float() - ref.float()).abs().max()))
     finally:
-        lib.seam_roi_align_set_lds(0)
+        lib.seam_roi_align_set_lds(2)
 
 
 def test_match_trunk_one_call_equals_the_launch_sequence(ops):

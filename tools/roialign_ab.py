@@ -16,7 +16,7 @@ rois = torch.cat([torch.cat([torch.full((32, 1), float(i)), b], 1) for i in rang
 scales = [0.25, 0.125, 0.0625, 0.03125]
 lib = _native.lib()
 out = {}
-for mode, name in ((0, "gather (one wave per bin)"), (1, "LDS-staged ROI row tiles")):
+for mode, name in ((0, "gather (one wave per bin)"), (1, "LDS-staged ROI row tiles"), (2, "LDS-staged ROI quadrants")):
     lib.seam_roi_align_set_lds(mode)
     for _ in range(3):
         y = ops.roi_align(feats, rois, scales, 14)
@@ -29,4 +29,4 @@ for mode, name in ((0, "gather (one wave per bin)"), (1, "LDS-staged ROI row til
     us = e0.elapsed_time(e1) * 1e3 / 20
     out[mode] = y
     print(f"{name:28s} {us:8.1f} us   output {y.numel() * y.element_size() / us / 1e3:7.0f} GB/s   ({len(rois)} ROIs, {dt})")
-print("bit-identical:", torch.equal(out[0], out[1]))
+print("bit-identical:", torch.equal(out[0], out[1]) and torch.equal(out[0], out[2]))
