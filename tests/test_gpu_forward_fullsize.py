@@ -95,6 +95,26 @@ def test_prefix_nms_paths_agree_800(world):
     _check_detections(outs[64], world["ref"], "detections 800x800 (prefix too small -> full NMS)")
 
 
+def test_two_frame_batch_800(world):
+    """Two different 800x800 frames in ONE call: the batched, padded post-process (13 000 candidates per image, shared prefix NMS
+    launch) must give each frame the detections it gets alone, and the second frame's must match the oracle as an exact set too."""
+    m, sd = world["m"], world["sd"]
+    img2 = torch.from_numpy(synth.frames(301, 1, 800, 800)[0])
+    with torch.no_grad():
+        both = m([world["img"].to(DEV), img2.to(DEV)])
+        alone = m([img2.to(DEV)])[0]
+        ofe, osz, opad = OM.extract_features([img2], sd)
+        oprops, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
+        ref2 = OM.detect(ofe, oprops, osz, sd, 0.1)[0]
+    for k in ("boxes", "labels", "scores"):
+        assert torch.equal(both[1][k], alone[k]), k                       # batch-invariant
+    partner = assert_same_set(ref2["boxes"], both[1]["boxes"], ref2["labels"], both[1]["labels"], ref2["scores"], both[1]["scores"],
+                              what="detections 800x800, second frame of a batch")
+    ok = partner >= 0
+    assert_close(both[1]["scores"].cpu()[partner[ok]], ref2["scores"][ok], rtol=1e-4)
+    _check_detections(both[0], world["ref"], "detections 800x800, first frame of a batch")
+
+
 def test_box_branch_on_oracle_proposals_800(world):
     """Stage isolation: the device box branch fed the ORACLE's proposals -- no RPN flip can leak into the comparison."""
     m = world["m"]
