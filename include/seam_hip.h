@@ -104,6 +104,21 @@ int seam_conv2d_dual_f32(const float* x1, const float* x2, const float* w_packed
                          const float* shift, float* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2,
                          int stride2, int K, int relu, seam_stream_t stream);
 
+/* Pointwise (1x1, stride 1, pad 0) convolution with a SHORT reduction, weights stationary in LDS (csrc/seam_pw.hip) -- the same
+ * contract as seam_conv2d_f32 / seam_conv2d_dual_f32 (stride2 = 1) / seam_conv2d_upres_f32 on those shapes [TV Bottleneck conv1 /
+ * conv3, FeaturePyramidNetwork.inner_blocks, MaskRCNNPredictor.conv5_mask], exact fp32 on v_mfma_f32_32x32x2_f32:
+ *   y[M,K] = act( [x | x2][M, C1 + C2] . w[K, C1 + C2]^T + shift [+ residual] )
+ * x [M,C1], x2 [M,C2] or NULL (C2 = 0), w row-major [K, C1 + C2] with any per-channel scale already folded in (one fp32
+ * rounding per weight), shift [K] (required).  res_mode 0: no residual; 1: residual [M,K]; 2: residual = coarse NHWC map
+ * [N,rH,rW,K] added through a nearest-neighbour upsample to the [Ho,Wo] output grid (M = N*Ho*Wo, ATen's index rule).
+ * Shapes served: C1, C2 multiples of 32, C1 + C2 <= 256, K a multiple of 64 (of 128 / 256 for the wider wave tiles), any M > 0;
+ * seam_conv1x1_sw_config returns 0 for anything else (MT*100 + NT of the wave tile otherwise) and the launcher then returns
+ * hipErrorInvalidValue.  An output pixel is one wave's fixed fma chain: results are deterministic and independent of M. */
+int seam_conv1x1_sw_config(int M, int C1, int C2, int K);
+int seam_conv1x1_sw_f32(const float* x, const float* x2, const float* w, const float* shift, const float* residual, float* y,
+                        int M, int C1, int C2, int K, int relu, int res_mode, int Ho, int Wo, int rH, int rW,
+                        seam_stream_t stream);
+
 /* fp16 twin of seam_conv2d_dual_f32 (x1, x2, w_packed, y fp16; C1 and C2 multiples of 64; fp32 accumulation and epilogue). */
 int seam_conv2d_dual_f16(const void* x1, const void* x2, const void* w_packed, const float* scale,
                          const float* shift, void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2,

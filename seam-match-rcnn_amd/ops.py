@@ -60,6 +60,8 @@ class PackedConv:
     u: Optional[torch.Tensor] = None  # fp32 stride-1 3x3 layers: Winograd F(2x2,3x3) weights (seam_pack_conv_weight_wino_f32)
     u24: Optional[torch.Tensor] = None  # ... and F(2x4,3x3) weights (seam_pack_conv_weight_wino24_f32)
     wn: Optional[torch.Tensor] = None   # fp32 1x1 layers with <= 16 outputs: register-resident weights of seam_linear_narrow_f32
+    ws: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C <= 256: row-major [K, C] weights (scale folded) of seam_conv1x1_sw_f32
+    shift_sw: Optional[torch.Tensor] = None   # ... and its shift vector (zeros when the layer has none)
 
 
 BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
@@ -121,6 +123,27 @@ def _wino_pays(lib, n, h, w, c, k, pad) -> bool:
     if f is None:
         f = _WINO_FILL[key] = int(lib.seam_wino_slot_fill_pct(256, h, w, c, k, pad))
     return f >= WINO_MIN_FILL
+
+
+# Short-reduction pointwise layers (1x1, stride 1, C <= 256) on the weights-stationary kernel of csrc/seam_pw.hip (SEAM_PW=0: implicit
+# GEMM).  Decided on the map geometry alone -- maps of >= SW_MIN_HW pixels, any batch -- so that an image's (or a ROI's) result never
+# depends on the batch it rides in (the two kernels round differently: folded scale, different k order).
+SW = _os.environ.get("SEAM_PW", "1") != "0"
+SW_MIN_HW = int(_os.environ.get("SEAM_PW_MIN_HW", "196"))
+
+
+def _sw_ok(pc: "PackedConv", h: int, w: int) -> bool:
+    return SW and pc.ws is not None and h * w >= SW_MIN_HW
+
+
+def _sw_launch(lib, x, x2, pc, residual, y, m, c1, c2, relu, res_mode=0, ho=0, wo=0, rh=0, rw=0):
+    _native.check(lib.seam_conv1x1_sw_f32(_ptr(x), _ptr(x2), _ptr(pc.ws), _ptr(pc.shift_sw), _ptr(residual), _ptr(y), m, c1, c2, pc.K,
+                                          int(relu), res_mode, ho, wo, rh, rw, _stream()), "seam_conv1x1_sw_f32")
+
+
+def _sw_variant(lib, m, c, k) -> str:
+    cfg = int(lib.seam_conv1x1_sw_config(m, c, 0, k))
+    return f"conv1x1_sw<{cfg // 100},{cfg % 100}>"
 
 
 # When set to a list, every conv launch is bracketed by HIP events on the launch stream and
@@ -194,7 +217,14 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
             and lib.seam_linear_narrow_supported(cs, K)):
         wn = torch.empty((64 * cs,), dtype=F32, device=weight.device)
         _native.check(lib.seam_pack_linear_narrow_f32(_ptr(weight), _ptr(wn), K, cs, _stream()), "seam_pack_linear_narrow_f32")
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn)
+    ws = shift_sw = None
+    if (dtype == F32 and mode in (0, 1) and R == 1 and S == 1 and stride == 1 and pad == 0 and cs == cin
+            and lib.seam_conv1x1_sw_config(1 << 20, cs, 0, K)):
+        # weights-stationary pointwise kernel (csrc/seam_pw.hip): plain row-major [K, C], the per-channel scale folded in
+        wm = (weight.permute(2, 3, 1, 0).reshape(K, cin) if transposed2x2 else weight.reshape(K, cin)).to(F32)
+        ws = (wm * scale[:, None] if scale is not None else wm).contiguous()
+        shift_sw = shift if shift is not None else torch.zeros((K,), dtype=F32, device=weight.device)
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw)
 
 
 def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -> PackedConv:
@@ -377,9 +407,12 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     lib = _native.lib()
     wino = pc.dtype == F32 and pc.u is not None and WINOGRAD and out_hw is None and _wino_pays(lib, n, h, w, c, pc.K, pc.pad)
     wino24 = wino and pc.u24 is not None and WINOGRAD24 and _wino24_pays(lib, n, h, w, c, pc.K, pc.pad)
+    sw = not narrow and pc.dtype == F32 and out_hw is None and _sw_ok(pc, h, w)
     if narrow:
         _native.check(lib.seam_linear_narrow_f32(_ptr(x), _ptr(pc.wn), _ptr(pc.shift), _ptr(y), n * h * w, c, pc.K, int(relu), _stream()),
                       "seam_linear_narrow_f32")
+    elif sw:
+        _sw_launch(lib, x, None, pc, residual, y, n * h * w, c, 0, relu, 1 if residual is not None else 0)
     elif wino24:
         _native.check(lib.seam_conv3x3_wino24_f32(_ptr(x), _ptr(pc.u24), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                                   n, h, w, c, pc.K, pc.pad, int(relu), _stream()), "seam_conv3x3_wino24_f32")
@@ -406,6 +439,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         tile = lib.seam_conv_tile_taps(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K, pc.R * pc.S)
         if narrow:
             variant = "linear_narrow"
+        elif sw:
+            variant = _sw_variant(lib, n * h * w, c, pc.K)
         elif wino24:
             variant = f"conv3x3_wino24<{lib.seam_wino24_variant(n, h, w, c, pc.K, pc.pad)}>"
         elif wino:
@@ -443,13 +478,17 @@ def conv2d_topdown(x: torch.Tensor, pc: PackedConv, top: torch.Tensor) -> torch.
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = _native.lib()
-    _native.check(lib.seam_conv2d_upres_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(top), _ptr(y),
-                                            n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, top.shape[1], top.shape[2], 0,
-                                            _stream()), "seam_conv2d_upres_f32")
+    sw = _sw_ok(pc, h, w) and h * w >= 64
+    if sw:
+        _sw_launch(lib, x, None, pc, top, y, n * h * w, c, 0, False, 2, ho, wo, top.shape[1], top.shape[2])
+    else:
+        _native.check(lib.seam_conv2d_upres_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(top), _ptr(y),
+                                                n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, top.shape[1], top.shape[2], 0,
+                                                _stream()), "seam_conv2d_upres_f32")
     if trace is not None:
         e1.record()
         tile = lib.seam_conv_tile_prec(0, n * ho * wo, pc.K)
-        trace.append((f"conv_igemm<float,{tile // 1000},{tile % 1000}>",
+        trace.append((_sw_variant(lib, n * h * w, c, pc.K) if sw else f"conv_igemm<float,{tile // 1000},{tile % 1000}>",
                       2.0 * n * ho * wo * pc.K * pc.R * pc.S * (pc.Cin or pc.Cstore), e0, e1,
                       (n, h, w, c, pc.K, pc.R, pc.stride),
                       float(4 * (x.numel() + pc.w.numel() + y.numel() + top.numel()))))
@@ -492,16 +531,20 @@ def conv2d_dual(x1: torch.Tensor, x2: torch.Tensor, pc: PackedConv, stride2: int
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = _native.lib()
-    fn = lib.seam_conv2d_dual_f32 if dt == F32 else lib.seam_conv2d_dual_f16
-    _native.check(fn(_ptr(x1), _ptr(x2), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, ho, wo, c1,
-                     h2, w2, c2, stride2, pc.K, int(relu), _stream()), "seam_conv2d_dual")
+    sw = dt == F32 and stride2 == 1 and (h2, w2) == (ho, wo) and _sw_ok(pc, ho, wo)
+    if sw:
+        _sw_launch(lib, x1, x2, pc, None, y, n * ho * wo, c1, c2, relu)
+    else:
+        fn = lib.seam_conv2d_dual_f32 if dt == F32 else lib.seam_conv2d_dual_f16
+        _native.check(fn(_ptr(x1), _ptr(x2), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, ho, wo, c1,
+                         h2, w2, c2, stride2, pc.K, int(relu), _stream()), "seam_conv2d_dual")
     if trace is not None:
         e1.record()
         tile = lib.seam_conv_tile_prec(0 if dt == F32 else 1, n * ho * wo, pc.K)
         if tile // 1000 == 256:
             tile = 128128
         es = x1.element_size()
-        trace.append((f"conv_igemm<{'float' if dt == F32 else '_Float16'},{tile // 1000},{tile % 1000}>", 2.0 * n * ho * wo * pc.K * (c1 + c2), e0, e1,
+        trace.append((_sw_variant(lib, n * ho * wo, c1 + c2, pc.K) if sw else f"conv_igemm<{'float' if dt == F32 else '_Float16'},{tile // 1000},{tile % 1000}>", 2.0 * n * ho * wo * pc.K * (c1 + c2), e0, e1,
                       (n, ho, wo, c1 + c2, pc.K, 1, 1),
                       float(es * (x1.numel() + n * ho * wo * c2 + pc.w.numel() + y.numel()))))
     return y
