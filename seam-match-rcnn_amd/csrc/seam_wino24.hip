@@ -269,14 +269,16 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     // lane offsets of positions nu = 0..3 and 4..5: the per-position 1 KiB steps then fit the instruction's 12-bit immediate, and the
     // scalar offset is one value per chunk (and n-tile).  Chunks past the end are not clamped: they read the next n-tile's first
     // chunk or fall outside the descriptor (zero fill), and are never used.
-    const int uoff[2] = {(xi * 6 * 64 + lane) * 16, (xi * 6 * 64 + lane) * 16 + 4096};
+    // (ONE lane offset, made opaque once per chunk: hipcc otherwise hoists the six "offset + nu KiB" sums out of the K loop, parks
+    //  them in AccVGPRs and pays a v_accvgpr_read -- a vector-ALU instruction, i.e. ~20 idle cycles of the fp32 matrix pipe -- per load)
+    int uoff0 = (xi * 6 * 64 + lane) * 16;
     constexpr int NBS = NT == 1 ? 2 : 1;     // weight register sets: NT = 2 keeps ONE that rolls (arch VGPRs are the limit there)
     f32x4 bfs[NBS][NT][6];
     auto load_b = [&](f32x4 (&bf)[NT][6], int nu, int chunk) {       // position nu of every n-tile
-        const int so = chunk * 24576;
+        const int so = chunk * 24576 + (nu >> 2) * 4096;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            bf[nt][nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff[nu >> 2] + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
+            bf[nt][nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff0 + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
     };
 
     // ---- input transform --------------------------------------------------------------------------------------------
@@ -299,8 +301,10 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     const f32x2 cb2 = {cb, cb};
     const f32x2 k4 = {4.f, 4.f}, km5 = {-5.f, -5.f}, km4 = {-4.f, -4.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
     f32x4 va[6];            // A fragments of the current chunk (rolling: overwritten pair by pair with the next chunk's)
+    f32x4 vb[2];            // NT = 2: the second set of positions 3, 4 (chunks alternate between va[3..4] and vb[0..1])
     f32x4 T0, T1, T2, T3, T4, T5;
     f32x4 xa[3], xb[3];
+    f32x4 ya[3], yb[3];     // NT = 2: the odd columns, so that all twelve reads of a chunk are in flight together
     auto rdA = [&](int buf) {            // columns 0, 2, 4
         const char* base = &raw[buf][rbase];
         xa[0] = *reinterpret_cast<const f32x4*>(base + oa);
@@ -318,6 +322,21 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
         xb[1] = *reinterpret_cast<const f32x4*>(base + ob + 3 * c1);
         xa[2] = *reinterpret_cast<const f32x4*>(base + oa + c1 + 16);
         xb[2] = *reinterpret_cast<const f32x4*>(base + ob + c1 + 16);
+    };
+    auto rdB2 = [&](int buf) {           // columns 1, 3, 5 into their own registers
+        const char* base = &raw[buf][rbase];
+        ya[0] = *reinterpret_cast<const f32x4*>(base + oa + c1);
+        yb[0] = *reinterpret_cast<const f32x4*>(base + ob + c1);
+        ya[1] = *reinterpret_cast<const f32x4*>(base + oa + 3 * c1);
+        yb[1] = *reinterpret_cast<const f32x4*>(base + ob + 3 * c1);
+        ya[2] = *reinterpret_cast<const f32x4*>(base + oa + c1 + 16);
+        yb[2] = *reinterpret_cast<const f32x4*>(base + ob + c1 + 16);
+    };
+    auto cTB2 = [&]() { T1 = fma4s(cb2, yb[0], ya[0]); T3 = fma4s(cb2, yb[1], ya[1]); T5 = fma4s(cb2, yb[2], ya[2]); };
+    auto cV34to = [&](f32x4& v3, f32x4& v4) {
+        const f32x4 c = sub4(T4, T2), d = sub4(T3, T1);
+        v3 = fma4s(k2, d, c);
+        v4 = fma4s(km2, d, c);
     };
     auto cTA = [&]() { T0 = fma4s(cb2, xb[0], xa[0]); T2 = fma4s(cb2, xb[1], xa[1]); T4 = fma4s(cb2, xb[2], xa[2]); };
     auto cTB = [&]() { T1 = fma4s(cb2, xb[0], xa[0]); T3 = fma4s(cb2, xb[1], xa[1]); T5 = fma4s(cb2, xb[2], xa[2]); };
@@ -347,6 +366,8 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define MF(nu, kk) do { _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { \
         acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[nu][kk], bcur[nt][nu][kk], acc[nu][nt], 0, 0, 0); if (nt + 1 < NT) SB(); } } while (0)
+#define MG(frag, nu, kk) do { _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { \
+        acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[kk], bcur[nt][nu][kk], acc[nu][nt], 0, 0, 0); if (nt + 1 < NT) SB(); } } while (0)
 
     // ---- prologue -------------------------------------------------------------------------------------------------
     load_raw(rset[0], 0);
@@ -364,7 +385,8 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
         load_raw(rset[0], 2);
     }
     __syncthreads();
-    rdA(0); cTA(); rdB(0); cTB(); cV05(); cV12();     // V3, V4 of chunk 0 are made in its first slot
+    rdA(0); cTA(); rdB(0); cTB(); cV05(); cV12();     // NT = 1: V3, V4 of chunk 0 are made in its first slot
+    if constexpr (NT == 2) cV34to(va[3], va[4]);
     __syncthreads();                                  // chunk 0 overwrites raw[0] right away
 
     // At the top of chunk t: raw[t&1] = patch(t) (already consumed), raw[(t+1)&1] = patch(t+1), rset[t&1] = patch(t+2) in
@@ -377,6 +399,7 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     // vector-memory counter retires in order, so a wait for a weight fragment also waits for every older load: with the
     // weights first, the (HBM-latency) patch loads of chunk t are not forced to complete before the top of chunk t+2.
     auto chunk = [&](int t, int par, f32x4 (&bcur)[NT][6], f32x4 (&bnext)[NT][6]) {
+        asm volatile("" : "+v"(uoff0));
         if constexpr (NT == 1) {
             SB(); MF(0, 0); A8(cV34());
             SB(); MF(5, 0); A8(rdA(par ^ 1));
@@ -404,32 +427,53 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
             SB(); MF(4, 3);
             SB();
         } else {
-            // two MFMAs per MF(): the weights of a position pair are re-loaded (for chunk t+1, into the same registers) right
-            // after its last MFMA, 32 MFMAs ahead of their use; the pieces sit two MFMAs apart
-            SB(); MF(0, 0); A8(cV34());
-            SB(); MF(5, 0); A8(rdA(par ^ 1));
+            // Two MFMAs per MF().  What tools/mfma_shadow_probe.hip measured (profiles/r04_mfma_shadow_probe.txt): in ONE wave no
+            // vector-ALU instruction overlaps an fp32 MFMA -- a group of k of them between two MFMAs idles the matrix pipe for
+            // ~17 + 4.5 k cycles -- while LDS reads, global loads and scalar instructions are free.  So the whole input
+            // transform of chunk t + 1 (36 packed ops) is ONE group, placed behind the 32 MFMAs of positions 0, 5, 1, 2 (whose
+            // fragments it overwrites); positions 3, 4 alternate between two register sets (va[3..4] / vb[0..1] by chunk
+            // parity), so nothing of the transform is carried across the chunk boundary; the twelve patch reads it needs are
+            // issued together, 8 MFMAs ahead.  The weights of a position pair are re-loaded (for chunk t + 1, into the same
+            // registers) right after its last MFMA.
+            SB(); MF(0, 0);
+            SB(); MF(5, 0);
             SB(); MF(0, 1);
-            SB(); MF(5, 1); A8(cTA());
-            SB(); MF(0, 2); A8(rdB(par ^ 1));
+            SB(); MF(5, 1);
+            SB(); MF(0, 2);
             SB(); MF(5, 2);
-            SB(); MF(0, 3); A8(cTB());
+            SB(); MF(0, 3);
             SB(); MF(5, 3);
-            SB(); MF(1, 0); A8(cV05());
-            SB(); MF(2, 0); A2(load_b(bcur, 0, t + 1));
-            SB(); MF(1, 1); A2(load_b(bcur, 5, t + 1));
-            SB(); MF(2, 1); A1(store_raw(rset[0], par));
-            SB(); MF(1, 2); A1(load_raw(rset[0], t + 3));
+            SB(); MF(1, 0); A2(load_b(bcur, 0, t + 1));
+            SB(); MF(2, 0); A2(load_b(bcur, 5, t + 1));
+            SB(); MF(1, 1); A1(store_raw(rset[0], par));
+            SB(); MF(2, 1); A1(load_raw(rset[0], t + 3));
+            SB(); MF(1, 2); A8(rdA(par ^ 1); rdB2(par ^ 1));
             SB(); MF(2, 2);
             SB(); MF(1, 3);
             SB(); MF(2, 3);
-            SB(); MF(3, 0); A8(cV12());
-            SB(); MF(4, 0); A2(load_b(bcur, 1, t + 1));
-            SB(); MF(3, 1); A2(load_b(bcur, 2, t + 1));
-            SB(); MF(4, 1);
-            SB(); MF(3, 2);
-            SB(); MF(4, 2);
-            SB(); MF(3, 3);
-            SB(); MF(4, 3); A2(load_b(bcur, 3, t + 1); load_b(bcur, 4, t + 1));
+            SB();
+            A8(cTA(); cTB2(); cV05(); cV12());
+            if (par == 0) {
+                A8(cV34to(vb[0], vb[1]));
+                SB(); MG(va[3], 3, 0); A2(load_b(bcur, 1, t + 1));
+                SB(); MG(va[4], 4, 0); A2(load_b(bcur, 2, t + 1));
+                SB(); MG(va[3], 3, 1);
+                SB(); MG(va[4], 4, 1);
+                SB(); MG(va[3], 3, 2);
+                SB(); MG(va[4], 4, 2);
+                SB(); MG(va[3], 3, 3);
+                SB(); MG(va[4], 4, 3); A2(load_b(bcur, 3, t + 1); load_b(bcur, 4, t + 1));
+            } else {
+                A8(cV34to(va[3], va[4]));
+                SB(); MG(vb[0], 3, 0); A2(load_b(bcur, 1, t + 1));
+                SB(); MG(vb[1], 4, 0); A2(load_b(bcur, 2, t + 1));
+                SB(); MG(vb[0], 3, 1);
+                SB(); MG(vb[1], 4, 1);
+                SB(); MG(vb[0], 3, 2);
+                SB(); MG(vb[1], 4, 2);
+                SB(); MG(vb[0], 3, 3);
+                SB(); MG(vb[1], 4, 3); A2(load_b(bcur, 3, t + 1); load_b(bcur, 4, t + 1));
+            }
             SB();
         }
         if (!(SEAM_W24_ABL & 4)) __syncthreads();
@@ -440,6 +484,7 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     }
 #undef SB
 #undef MF
+#undef MG
 #undef A1
 #undef A2
 #undef A8
