@@ -272,7 +272,7 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     // (ONE lane offset, made opaque once per chunk: hipcc otherwise hoists the six "offset + nu KiB" sums out of the K loop, parks
     //  them in AccVGPRs and pays a v_accvgpr_read -- a vector-ALU instruction, i.e. ~20 idle cycles of the fp32 matrix pipe -- per load)
     int uoff0 = (xi * 6 * 64 + lane) * 16;
-    constexpr int NBS = NT == 1 ? 2 : 1;     // weight register sets: NT = 2 keeps ONE that rolls (arch VGPRs are the limit there)
+    constexpr int NBS = 2;                   // weight register sets: chunk t + 1's are requested at the top of chunk t
     f32x4 bfs[NBS][NT][6];
     auto load_b = [&](f32x4 (&bf)[NT][6], int nu, int chunk) {       // position nu of every n-tile
         const int so = chunk * 24576 + (nu >> 2) * 4096;
@@ -433,18 +433,18 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
             // transform of chunk t + 1 (36 packed ops) is ONE group, placed behind the 32 MFMAs of positions 0, 5, 1, 2 (whose
             // fragments it overwrites); positions 3, 4 alternate between two register sets (va[3..4] / vb[0..1] by chunk
             // parity), so nothing of the transform is carried across the chunk boundary; the twelve patch reads it needs are
-            // issued together, 8 MFMAs ahead.  The weights of a position pair are re-loaded (for chunk t + 1, into the same
-            // registers) right after its last MFMA.
-            SB(); MF(0, 0);
-            SB(); MF(5, 0);
-            SB(); MF(0, 1);
-            SB(); MF(5, 1);
-            SB(); MF(0, 2);
-            SB(); MF(5, 2);
+            // issued together, 8 MFMAs ahead.  Two weight register sets (the arch file has room: 162 of 256 were in use): chunk
+            // t + 1's twelve fragments are requested at the top of chunk t, ahead of the patch loads in the in-order vmcnt queue.
+            SB(); MF(0, 0); A2(load_b(bnext, 0, t + 1));
+            SB(); MF(5, 0); A2(load_b(bnext, 5, t + 1));
+            SB(); MF(0, 1); A2(load_b(bnext, 1, t + 1));
+            SB(); MF(5, 1); A2(load_b(bnext, 2, t + 1));
+            SB(); MF(0, 2); A2(load_b(bnext, 3, t + 1));
+            SB(); MF(5, 2); A2(load_b(bnext, 4, t + 1));
             SB(); MF(0, 3);
             SB(); MF(5, 3);
-            SB(); MF(1, 0); A2(load_b(bcur, 0, t + 1));
-            SB(); MF(2, 0); A2(load_b(bcur, 5, t + 1));
+            SB(); MF(1, 0);
+            SB(); MF(2, 0);
             SB(); MF(1, 1); A1(store_raw(rset[0], par));
             SB(); MF(2, 1); A1(load_raw(rset[0], t + 3));
             SB(); MF(1, 2); A8(rdA(par ^ 1); rdB2(par ^ 1));
@@ -455,24 +455,24 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
             A8(cTA(); cTB2(); cV05(); cV12());
             if (par == 0) {
                 A8(cV34to(vb[0], vb[1]));
-                SB(); MG(va[3], 3, 0); A2(load_b(bcur, 1, t + 1));
-                SB(); MG(va[4], 4, 0); A2(load_b(bcur, 2, t + 1));
+                SB(); MG(va[3], 3, 0);
+                SB(); MG(va[4], 4, 0);
                 SB(); MG(va[3], 3, 1);
                 SB(); MG(va[4], 4, 1);
                 SB(); MG(va[3], 3, 2);
                 SB(); MG(va[4], 4, 2);
                 SB(); MG(va[3], 3, 3);
-                SB(); MG(va[4], 4, 3); A2(load_b(bcur, 3, t + 1); load_b(bcur, 4, t + 1));
+                SB(); MG(va[4], 4, 3);
             } else {
                 A8(cV34to(va[3], va[4]));
-                SB(); MG(vb[0], 3, 0); A2(load_b(bcur, 1, t + 1));
-                SB(); MG(vb[1], 4, 0); A2(load_b(bcur, 2, t + 1));
+                SB(); MG(vb[0], 3, 0);
+                SB(); MG(vb[1], 4, 0);
                 SB(); MG(vb[0], 3, 1);
                 SB(); MG(vb[1], 4, 1);
                 SB(); MG(vb[0], 3, 2);
                 SB(); MG(vb[1], 4, 2);
                 SB(); MG(vb[0], 3, 3);
-                SB(); MG(vb[1], 4, 3); A2(load_b(bcur, 3, t + 1); load_b(bcur, 4, t + 1));
+                SB(); MG(vb[1], 4, 3);
             }
             SB();
         }
