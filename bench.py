@@ -407,9 +407,23 @@ def main():
                 ts.append(time.perf_counter() - t0)
             extras["full_forward_ms_per_clip"] = round(1e3 * sorted(ts[1:])[1], 3)
             extras["full_forward_detections_per_frame"] = [int(len(d["scores"])) for d in det]
+            del det
+            tb = []
+            for i in range(3):                                                # the same forward on the step's whole batch (B clips)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                detb = model(frame_list)
+                torch.cuda.synchronize()
+                tb.append(time.perf_counter() - t0)
+            extras["full_forward_clips_per_s"] = round(B / min(tb[1:]), 3)
+            extras["full_forward_batched_ms_per_clip"] = round(1e3 * min(tb[1:]) / B, 3)
+            extras["full_forward_batched_detections"] = int(sum(len(d["scores"]) for d in detb))
+            del detb
             extras["extras_note"] = ("value_clips1: the same step with ONE clip per step (latency-oriented); "
                                      "full_forward_ms_per_clip: median of 3 of model(10 frames) with RPN proposals, box head, "
-                                     "per-class NMS, mask + match branches and mask paste (not part of `value`)")
+                                     "per-class NMS, mask + match branches and mask paste (not part of `value`); "
+                                     "full_forward_clips_per_s: the same drop-in forward on the step's batch of clips "
+                                     "(clips_per_step_per_gpu x frames images in ONE model(images) call), best of 2 after a warm-up")
 
     match_stage = None
     if rank == 0 and not stub and wl["rank"] == "topk" and not args.graph:
@@ -469,6 +483,13 @@ def main():
         if match_stage is not None:
             line["match_stage"] = match_stage
         if roofline is not None:
+            # end to end: MFMA work issued for the step's convolutions / the TIMED step (all streams, every non-conv kernel and
+            # launch gap included) / peak -- the fraction of the fp32-MFMA roof the whole step sustains
+            ws = roofline["issued_tflop_per_step"] / (ms_per_step * 1e-3) / roofline["peak"]
+            roofline["whole_step"] = {"frac": round(ws, 4), "issued_tflop_per_step": roofline["issued_tflop_per_step"],
+                                      "ms_per_step": round(ms_per_step, 3),
+                                      "is": "sum over conv launches of algorithmic FLOP x mfma_issue_ratio, / ms_per_step of the timed "
+                                            "steps / peak"}
             line["roofline"] = roofline
         if cpu is not None:
             line["cpu_baseline"] = cpu
@@ -486,6 +507,19 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------------ roofline
+def mfma_issue_ratio(variant):
+    """MFMA multiplies issued per algorithmic multiply-accumulate of the direct convolution, and the algorithm's name."""
+    if variant.startswith("conv3x3_wino24"):
+        return 1.0 / 3.0, "Winograd F(2x4,3x3): 24 MFMA multiplies per 2x4 output tile and channel pair instead of 72"
+    if variant.startswith("conv3x3_wino"):
+        return 1.0 / 2.25, "Winograd F(2x2,3x3): 16 MFMA multiplies per 2x2 output tile and channel pair instead of 36"
+    if variant.startswith("conv_igemm_bx3"):
+        return 3.0, "split-bf16: 3 bf16 MFMAs per fp32 product (hi*hi + hi*lo + lo*hi)"
+    if variant.startswith("conv1x1_sw"):
+        return 1.0, "weights-stationary pointwise GEMM: one MFMA multiply per algorithmic multiply"
+    return 1.0, "implicit GEMM: one MFMA multiply per algorithmic multiply"
+
+
 def roofline_leg(step, dtype):
     """One instrumented step: every conv launch bracketed by HIP events on its launch stream (ops.CONV_TRACE).  The step runs on
     ONE stream (the timed steps overlap two batch halves on two streams, which stretches every kernel's own duration: a per-kernel
@@ -517,15 +551,7 @@ def roofline_leg(step, dtype):
     n, fl, sec, alg_bytes = per[dom]
     algorithmic = fl / sec / 1e12
     peak = FP32_MFMA_PEAK_TFLOPS if dtype == "f32" else F16_MFMA_PEAK_TFLOPS
-    # MFMA multiplies issued per algorithmic multiply-accumulate of the direct convolution
-    if dom.startswith("conv3x3_wino24"):
-        issue, algo = 1.0 / 3.0, "Winograd F(2x4,3x3): 24 MFMA multiplies per 2x4 output tile and channel pair instead of 72"
-    elif dom.startswith("conv3x3_wino"):
-        issue, algo = 1.0 / 2.25, "Winograd F(2x2,3x3): 16 MFMA multiplies per 2x2 output tile and channel pair instead of 36"
-    elif dom.startswith("conv_igemm_bx3"):
-        issue, algo = 3.0, "split-bf16: 3 bf16 MFMAs per fp32 product (hi*hi + hi*lo + lo*hi)"
-    else:
-        issue, algo = 1.0, "implicit GEMM: one MFMA multiply per algorithmic multiply"
+    issue, algo = mfma_issue_ratio(dom)
     achieved = algorithmic * issue
     src, traffic, busy = pmc_fields(dom) if dtype == "f32" else (None, None, None)
 
@@ -546,6 +572,7 @@ def roofline_leg(step, dtype):
             "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
             "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
             "conv_ms_per_step": round(1e3 * sum(v[2] for v in per.values()), 3),
+            "issued_tflop_per_step": round(sum(v[1] * mfma_issue_ratio(k)[0] for k, v in per.items()) / 1e12, 4),
             "other_variants": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[2], 3), "algorithmic_TFLOP/s": rate(v)}
                                for k, v in per.items() if k != dom}}
 

@@ -54,7 +54,15 @@ constexpr int WCAP = 512;         // per-wave candidate buffer in LDS (a tile th
 constexpr int LCAP = 4096;        // candidates of one query that pairmf_final can hold in LDS
 constexpr int RB = 32;            // candidates re-scored per batch in pairmf_final
 constexpr int RLD = D + 4;        // LDS row stride of the re-scoring batch (16-byte aligned rows, 2-way conflicts at most)
-constexpr float GAMMA = 300.0f * 5.9604645e-8f;   // >= (n + 2) u / (1 - (n + 2) u) for the n = 256-term fp32 chains below
+constexpr int PAIRMF_MAX_K = 64;                   // seam_pair_topk_mfma_max_k()
+constexpr int PAIRMF_KK_MAX = ((PAIRMF_MAX_K + 12 + 7) / 8) * 8;      // pairmf_kk(PAIRMF_MAX_K) = 80 candidates per query at most
+// gamma_n = n u / (1 - n u) of the n ~ 261-rounding fp32 chains below, with ~2x headroom (512 u instead of ~261 u: the candidate lists
+// barely change, eps stays far below the kk - k margin).  Rounding model assumed: every product and add of v_mfma_f32_16x16x4_f32 and of
+// the VALU chains rounds to nearest with |delta| <= u = 2^-24, denormal results kept (gfx950 default mode for MFMA and for this file).
+// ABS_EPS covers what a purely relative bound does not: terms whose products underflow (d * d or w * b below FLT_MIN lose up to one
+// denormal ulp each, 2 x 256 terms).
+constexpr float GAMMA = 512.0f * 5.9604645e-8f;
+constexpr float ABS_EPS = 1024.0f * 1.17549435e-38f;
 
 __device__ __forceinline__ float key_to_float(unsigned key) {
     return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(512) void pairmf_kernel(const MfArgs p) {
 // ---------------------------------------------------------------------------------------------------------------- 3. thresholds
 __global__ __launch_bounds__(256) void pairmf_thresh(const float* __restrict__ dense, float* __restrict__ tau, int Q, int kk) {
     __shared__ TopkShared sh;
-    __shared__ unsigned surv[4][64];                // kk <= 64 survivors per wave
+    __shared__ unsigned surv[4][PAIRMF_KK_MAX];     // kk survivors per wave (kk = pairmf_kk(k) <= PAIRMF_KK_MAX, checked by the launchers)
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (q >= Q) {                                   // padding queries never collect candidates
         if (tid == 0) tau[q] = INFINITY;
@@ -363,11 +371,15 @@ __global__ __launch_bounds__(256) void pairmf_thresh(const float* __restrict__ d
     if (lane < (int)krem) surv[wid][base + lane] = T;     // base + krem == kk
     __syncthreads();
     if (wid == 0) {
-        unsigned k2[4];
+        constexpr int P2 = (4 * PAIRMF_KK_MAX + 63) / 64;       // keys per lane of the second level: all 4 kk survivors
+        unsigned k2[P2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) k2[i] = (i * 64 + lane < 4 * kk) ? (&surv[0][0])[(i * 64 + lane) / kk * 64 + (i * 64 + lane) % kk] : 0u;
+        for (int i = 0; i < P2; ++i) {
+            const int e = i * 64 + lane;
+            k2[i] = e < 4 * kk ? surv[e / kk][e % kk] : 0u;
+        }
         unsigned kr2;
-        const unsigned T2 = wave_kth<4>(k2, 4 * kk, kk, sh.hist, kr2);
+        const unsigned T2 = wave_kth<P2>(k2, 4 * kk, kk, sh.hist, kr2);
         if (lane == 0) tau[q] = key_to_float(T2);
     }
 }
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(256) void pairmf_final(const FinalArgs p) {
                 // biases); so d_j <= m + eps < d(k-th winner) strictly.  Any NaN makes the comparison false.
                 const float m = fmaxf(key_to_float(T), tau_q);
                 const float sp = sqrtf(qP_q) + sqrtf(rmax);
-                const float eps = 2.f * GAMMA * (sp * sp + fabsf(b0) + fabsf(b1));
+                const float eps = 2.f * GAMMA * (sp * sp + fabsf(b0) + fabsf(b1)) + ABS_EPS;
                 const float dk = key_to_float(mykey);
                 if (!(dk > m + eps)) bad_s = 1;
             }
@@ -534,9 +546,10 @@ int g_num_cu = 0;
 extern "C" {
 
 int seam_pair_topk_mfma_min_gallery(void) { return 2 * NS_ROWS; }
-int seam_pair_topk_mfma_max_k(void) { return 64; }
+int seam_pair_topk_mfma_max_k(void) { return PAIRMF_MAX_K; }
 
 static int pairmf_kk(int k) { return ((k + 12 + 7) / 8) * 8; }
+static_assert(((PAIRMF_MAX_K + 12 + 7) / 8) * 8 <= PAIRMF_KK_MAX, "pairmf_thresh sizes its survivor lists by PAIRMF_KK_MAX");
 static int pairmf_cap(int G, int kk) { (void)G; (void)kk; return 1024; }      // overflow list of a query
 static int pairmf_rows_per_block(int G) {
     int rpb = (G + g_num_cu - 1) / g_num_cu;

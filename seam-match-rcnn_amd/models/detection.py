@@ -464,6 +464,23 @@ def batched_nms_images(boxes, scores, idxs, valid, thr, top_n, prefix: int = 0):
     return order, full, exact
 
 
+def compact_rows(sel: torch.Tensor, vals, cap: int):
+    """Per row of ``sel`` [B,m] (at most ``cap`` True entries each): the selected entries of every tensor in ``vals``
+    ([B,m] or [B,m,c]) moved to the front, in order -> tensors [B,cap(,c)] (zeros behind the selected ones).  Device-side
+    compaction by prefix sum + scatter: no boolean-mask indexing, hence no host synchronisation."""
+    b = sel.shape[0]
+    pos = sel.cumsum(1) - 1
+    idx = torch.where(sel, pos, pos.new_full((), cap))          # unselected entries go to a dump slot behind the row
+    out = []
+    for v in vals:
+        if v.dim() == 3:
+            o = v.new_zeros((b, cap + 1, v.shape[2])).scatter_(1, idx[..., None].expand(-1, -1, v.shape[2]), v)
+        else:
+            o = v.new_zeros((b, cap + 1)).scatter_(1, idx, v)
+        out.append(o[:, :cap])
+    return out
+
+
 class RegionProposalNetwork(nn.Module):
     def __init__(self, pre_nms_top_n_test=1000, post_nms_top_n_test=1000, nms_thresh=0.7, min_size=1e-3,
                  pre_nms_top_n_train=2000, post_nms_top_n_train=2000):
@@ -485,11 +502,15 @@ class RegionProposalNetwork(nn.Module):
             self._anchor_cache[key] = [torch.from_numpy(a).to(device) for a in grid_anchors(padded_hw, feat_hws)]
         return self._anchor_cache[key]
 
-    def forward(self, feats: "OrderedDict[str, torch.Tensor]", image_sizes, padded_hw):
+    def forward(self, feats: "OrderedDict[str, torch.Tensor]", image_sizes, padded_hw, padded_out: bool = False):
         """RegionProposalNetwork.filter_proposals for the whole batch: per-level top-k + decode + clip + sigmoid in ONE
         launch per level (``seam_rpn_topk_decode_f32``: a radix select over the logits in place, no device sort), small-box
         filter, per-level NMS, first post_nms_top_n -- one host synchronisation (the variable-length split of the
-        result) instead of ~20 per image."""
+        result) instead of ~20 per image.
+
+        ``padded_out``: return ``(boxes [N, post_nms_top_n, 4], counts [N] int64 on the device)`` instead of the list -- the
+        proposals of an image at the front of its row, zeros behind -- with NO host synchronisation (``VideoMatchRCNN.forward``
+        hands this form to its own RoI heads: the whole drop-in forward then waits for the device once, at the detections)."""
         fl = list(feats.values())
         n = fl[0].shape[0]
         dev = fl[0].device
@@ -512,6 +533,8 @@ class RegionProposalNetwork(nn.Module):
         valid = ((bx[..., 2] - bx[..., 0]) >= self.min_size) & ((bx[..., 3] - bx[..., 1]) >= self.min_size)
         order, sel, _ = batched_nms_images(bx, sc, lv, valid, self.nms_thresh, self.post_nms_top_n)
         kept = torch.gather(bx, 1, order[..., None].expand(-1, -1, 4))
+        if padded_out:
+            return compact_rows(sel, [kept], self.post_nms_top_n)[0].contiguous(), sel.sum(1)
         counts = sel.sum(1).tolist()                                                    # the one sync
         return list(kept[sel].split(counts, 0))
 

@@ -70,7 +70,9 @@ class TemporalRoIHeads(nn.Module):
 
     # ref :154-205 -- softmax, decode (weights 10,10,5,5), clip, drop background, score > thr,
     # remove small, per-class NMS, top-k.  Decode/clip and the NMS bit-matrix + scan are HIP kernels.
-    def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes):
+    def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes, valid_counts=None):
+        """``valid_counts`` ([N] int64 on the device, padded-proposal form): only the first valid_counts[i] proposals of image i
+        exist; the rest of its row is padding and can never be detected."""
         num_classes = class_logits.shape[-1]
         counts = [len(p) for p in proposals]
         n_img = len(counts)
@@ -95,6 +97,9 @@ class TemporalRoIHeads(nn.Module):
         img = torch.repeat_interleave(torch.arange(n_img, device=dev), torch.tensor(counts, device=dev))
         pb[img, row] = boxes.view(-1, num_classes, 4)
         ps[img, row] = pred_scores
+        if valid_counts is not None:
+            real = torch.arange(pmax, device=dev)[None] < valid_counts.to(dev)[:, None]
+            ps = torch.where(real[..., None], ps, ps.new_full((), -1.0))
         pb, ps = pb[:, :, 1:].reshape(n_img, c, 4), ps[:, :, 1:].reshape(n_img, c)           # drop background
         labels = torch.arange(1, num_classes, device=dev).repeat(pmax)[None].expand(n_img, -1)
         valid = (ps > self.score_thresh) & ((pb[..., 2] - pb[..., 0]) >= 1e-2) & ((pb[..., 3] - pb[..., 1]) >= 1e-2)
@@ -110,13 +115,19 @@ class TemporalRoIHeads(nn.Module):
         stats = torch.cat([sel.sum(1), exact.to(torch.int64)]).tolist()                      # one sync
         if not all(stats[n_img:]):
             if big:                         # beyond the batched NMS kernel's per-image capacity (e.g. 91 classes): per-image path
+                if valid_counts is not None:    # padded proposals (every row has pmax entries): padding never passes the score filter
+                    pred_scores = torch.where(real.reshape(-1, 1), pred_scores, pred_scores.new_full((), -1.0))
                 return self._postprocess_per_image(boxes.view(-1, num_classes, 4), pred_scores, counts)
             order, sel, _ = det.batched_nms_images(pb, ps, labels, valid, self.nms_thresh, self.detections_per_img)
             stats = sel.sum(1).tolist()
         kept = stats[:n_img]
         kb = torch.gather(pb, 1, order[..., None].expand(-1, -1, 4))
         ks, kl = torch.gather(ps, 1, order), torch.gather(labels, 1, order)
-        return (list(kb[sel].split(kept, 0)), list(ks[sel].split(kept, 0)), list(kl[sel].split(kept, 0)))
+        # survivors to the front of each row on the device; the per-image results are views of length kept[i] (a boolean-mask
+        # index here would be a second, hidden synchronisation)
+        kb, ks, kl = det.compact_rows(sel, [kb, ks, kl], self.detections_per_img)
+        return ([kb[i, :k] for i, k in enumerate(kept)], [ks[i, :k] for i, k in enumerate(kept)],
+                [kl[i, :k] for i, k in enumerate(kept)])
 
     def _postprocess_per_image(self, boxes, scores, counts):
         """Same rule as above for candidate sets too large for one batched NMS launch: filter first (one host
@@ -137,11 +148,16 @@ class TemporalRoIHeads(nn.Module):
         return out_b, out_s, out_l
 
     def detect(self, features, proposals, image_shapes):
-        """box branch (ref :225-253)."""
+        """box branch (ref :225-253).  ``proposals``: the reference's list of [k_i,4] tensors, or the padded form
+        ``(boxes [N,P,4], counts [N])`` of ``RegionProposalNetwork.forward(padded_out=True)`` (no host sync before the detections)."""
+        valid_counts = None
+        if isinstance(proposals, tuple):
+            padded, valid_counts = proposals
+            proposals = list(padded.unbind(0))
         box_features = self.box_roi_pool(features, proposals, image_shapes)
         box_features = self.box_head(box_features)
         class_logits, box_regression = self.box_predictor(box_features)
-        boxes, scores, labels = self.postprocess_detections(class_logits, box_regression, proposals, image_shapes)
+        boxes, scores, labels = self.postprocess_detections(class_logits, box_regression, proposals, image_shapes, valid_counts)
         result = []
         for i in range(len(boxes)):
             if boxes[i].numel() > 0:
@@ -226,6 +242,7 @@ class TemporalRoIHeads(nn.Module):
 
 class VideoMatchRCNN(nn.Module):
     roi_heads_cls = TemporalRoIHeads
+    ONE_SYNC = True
 
     def __init__(self, backbone, num_classes, n_frames=3, min_size=800, max_size=1333,
                  rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000, rpn_nms_thresh=0.7,
@@ -272,7 +289,9 @@ class VideoMatchRCNN(nn.Module):
         if not images:
             return []
         feats, sizes, orig, padded = self.extract_features([i.detach() for i in images])
-        proposals = self.rpn(feats, sizes, padded)
+        # padded proposals: the forward synchronises with the device ONCE, at the detection counts (ONE_SYNC = False: the
+        # reference's list form, one more sync at the RPN's variable-length split; identical results, tested)
+        proposals = self.rpn(feats, sizes, padded, padded_out=self.ONE_SYNC)
         if targets is not None:        # GT boxes arrive in original-image pixels -> resized frame
             targets = [dict(t, boxes=det.GeneralizedRCNNTransform.rescale_boxes(
                 t["boxes"].to(feats["0"].device).to(torch.float32), o, s)) for t, s, o in zip(targets, sizes, orig)]

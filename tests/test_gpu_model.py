@@ -334,3 +334,43 @@ def test_hip_graph_replay_matches_eager(model_and_state):
         torch.cuda.synchronize()
         eager = step(new)
     assert torch.equal(gout[0], eager[0]) and torch.equal(gout[1], eager[1])
+
+
+def test_one_sync_forward_equals_list_form(model_and_state):
+    """VideoMatchRCNN.forward hands the RPN's proposals to its RoI heads in the padded form (one device synchronisation per
+    forward, at the detection counts); the reference's list form (ONE_SYNC = False) must give the same outputs bit for bit,
+    on a mixed batch (images with different proposal counts) and with a score threshold nothing passes (fallback boxes)."""
+    m, _ = model_and_state
+    m.transform.min_size, m.transform.max_size = 192, 256
+    imgs = [torch.from_numpy(synth.frames(50 + i, 1, 192, 256)[0]).to(dev()) for i in range(3)]
+    imgs[1] = imgs[1][:, :128, :160].contiguous()              # a smaller image: fewer anchors, fewer proposals
+    old = m.roi_heads.score_thresh
+    try:
+        for thr in (old, 2.0):
+            m.roi_heads.score_thresh = thr
+            outs = []
+            for one in (True, False):
+                type(m).ONE_SYNC = one
+                with torch.no_grad():
+                    outs.append(m(imgs))
+            for a, b in zip(*outs):
+                assert a.keys() == b.keys()
+                for k in a:
+                    assert torch.equal(a[k], b[k]), k
+    finally:
+        type(m).ONE_SYNC = True
+        m.roi_heads.score_thresh = old
+
+
+def test_padded_proposals_match_the_list(model_and_state):
+    """RegionProposalNetwork.forward(padded_out=True): row i = the list form's proposals of image i, zeros behind."""
+    m, _ = model_and_state
+    m.transform.min_size, m.transform.max_size = 192, 256
+    imgs = [torch.from_numpy(synth.frames(60 + i, 1, 192, 256)[0]).to(dev()) for i in range(2)]
+    with torch.no_grad():
+        feats, sizes, _, padded = m.extract_features(imgs)
+        lst = m.rpn(feats, sizes, padded)
+        pb, pc = m.rpn(feats, sizes, padded, padded_out=True)
+    assert pb.shape == (2, m.rpn.post_nms_top_n, 4) and pc.tolist() == [len(p) for p in lst]
+    for i, p in enumerate(lst):
+        assert torch.equal(pb[i, :len(p)], p) and not bool(pb[i, len(p):].any())
