@@ -224,6 +224,8 @@ def main():
     B = args.clips
     lo, hi = retrieval.shard_range(G, rank, world)
     bank_shard = torch.from_numpy(synth.gallery(7, G)[lo:hi]).to(dev)        # this rank's rows of the product-descriptor bank
+    # test hook (stub runs only): this rank ends up with a DIFFERENT bank than its peers -- exercises the pre-timing check
+    corrupt = stub and os.environ.get("SEAM_BENCH_TEST_CORRUPT_RANK") == str(rank)
     gathers = []                                                             # timed all-gathers of the measured steps
     model = ta = frame_list = rois = types = ids = side = None
     if not stub:
@@ -255,7 +257,11 @@ def main():
         if stub:                                                                 # test hook: the exchange step alone, on CPU tensors
             pending = retrieval.gather_product_bank(bank_shard, G, force=multi)
             time.sleep(0.002 * (1 + rank))
-            return None, None, None, None, None, pending.wait()
+            got = pending.wait()
+            if corrupt:
+                got = got.clone()
+                got[0, 0] += 1.0
+            return None, None, None, None, None, got
         pending = retrieval.gather_product_bank(bank_shard, G, side_stream=side, timed=timed_gather, force=multi)   # overlaps the extractor
         if timed_gather and pending.events is not None:
             gathers.append(pending)
@@ -294,14 +300,30 @@ def main():
         with torch.no_grad(), torch.cuda.graph(graph):
             graph_out = step()
         run = graph.replay
+    def bank_identical(bank):
+        """the gathered bank must be the same [G,256] bits on every rank: min == max over ranks of a row-weighted integer checksum"""
+        wts = torch.arange(1, bank.shape[0] + 1, device=dev, dtype=torch.int64)
+        cs = (bank.contiguous().view(torch.int32).to(torch.int64).sum(1) * wts).sum().reshape(1)   # exact: order-independent integers
+        lo_cs, hi_cs = cs.clone(), cs.clone()
+        dist.all_reduce(lo_cs, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_cs, op=dist.ReduceOp.MAX)
+        return bool(lo_cs.item() == hi_cs.item()) and tuple(bank.shape) == (G, 256)
+
     log("warmup")
     last = None
     with torch.no_grad():
         for _ in range(args.warmup):
-            run()
+            last = run()
             dsync()
             log("warmup step done")
         sync_all()
+        if multi and last is not None and not args.graph:
+            # fail fast, BEFORE anything is timed: a rank whose all-gathered bank differs would time a different problem
+            # (every rank takes part in the two reductions and reaches the same verdict, so all of them exit together)
+            if not bank_identical(last[5]):
+                raise SystemExit(f"bench.py: rank {rank}: the all-gathered product bank differs between ranks after the warm-up "
+                                 f"steps -- refusing to time (check the shard ranges / the collective)")
+            log("bank identical on all ranks (pre-timing check)")
         log("timing")
         state["timed"] = multi and not args.graph
         t0 = time.perf_counter()
@@ -320,14 +342,7 @@ def main():
         dist.all_gather_into_tensor(every, mine)
         per_rank_ms = [round(1e3 * float(e) / args.steps, 3) for e in every.tolist()]
         elapsed = float(every.max().item())                                     # the contract's MAX over ranks
-        # the gathered bank must be the same [G,256] bits on every rank: min == max over ranks of a row-weighted integer checksum
-        bank = last[5]
-        wts = torch.arange(1, bank.shape[0] + 1, device=dev, dtype=torch.int64)
-        cs = (bank.contiguous().view(torch.int32).to(torch.int64).sum(1) * wts).sum().reshape(1)   # exact: order-independent integers
-        lo_cs, hi_cs = cs.clone(), cs.clone()
-        dist.all_reduce(lo_cs, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi_cs, op=dist.ReduceOp.MAX)
-        bank_agree = bool(lo_cs.item() == hi_cs.item()) and tuple(bank.shape) == (G, 256)
+        bank_agree = bank_identical(last[5])            # ... and again on the last timed step's bank
 
     ms_per_step = 1e3 * elapsed / args.steps
     log(f"timed: {ms_per_step:.2f} ms/step")

@@ -199,9 +199,12 @@ int seam_roi_align_f16(const void* feat0, const void* feat1, const void* feat2, 
                        int k_min, const float* rois, const int* levels, void* out, int K, int P,
                        int sampling_ratio, seam_stream_t stream);   /* fp16 maps in, fp16 out */
 
-/* Which kernel the two entry points above launch (process-wide; env SEAM_ROIALIGN_LDS at first use): 2 (default) = LDS-staged ROI
- * quadrant tiles, 1 = row-staged tiles, 0 = one wave per bin gathering its 16 taps from L1/L2 (also what any shape outside
- * sampling_ratio 2, P <= 16, C % 64 == 0 takes).  Bit-identical results; measurements in profiles/r03_roialign_ab.txt. */
+/* TEST / BENCHMARK HOOK ONLY -- not part of the per-stream thread-safety contract of this header: a process-wide selector of the
+ * kernel the two entry points above launch (also env SEAM_ROIALIGN_LDS at first use): 2 (default) = LDS-staged ROI quadrant tiles,
+ * 1 = row-staged tiles, 0 = one wave per bin gathering its 16 taps from L1/L2 (also what any shape outside sampling_ratio 2,
+ * P <= 16, C % 64 == 0 takes).  All three give bit-identical results, so a concurrent change can never alter an output -- but
+ * production callers should not call it (tools/roialign_ab.py and tests/test_gpu_ops.py do); measurements in
+ * profiles/r03_roialign_ab.txt. */
 void seam_roi_align_set_lds(int on);
 
 /* Layout bridges at the module boundary: x [B,C,L] <-> y [B,L,C]. */

@@ -103,3 +103,13 @@ def test_self_launch_branch_with_one_rank():
 def test_rank_count_mismatch_is_an_error():
     r = _run(["--gpus", "3", "--stub-step", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "--gpus 3" in r.stderr
+
+
+def test_two_ranks_refuse_to_time_a_diverging_bank():
+    """A rank whose all-gathered bank differs from its peers' makes EVERY rank exit before the timed region, with a clear message
+    and no result line (test hook SEAM_BENCH_TEST_CORRUPT_RANK, stub runs only)."""
+    r = _run(["--gpus", "2", "--stub-step", "--workload", "c4", "--steps", "3", "--warmup", "1", "--clips", "2"],
+             {"SEAM_BENCH_TEST_CORRUPT_RANK": "1"})
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "differs between ranks after the warm-up" in r.stderr and "refusing to time" in r.stderr

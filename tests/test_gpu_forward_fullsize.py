@@ -3,8 +3,10 @@ top-1000, 5 x 1000 candidates into the RPN NMS, 1000 proposals through the box h
 prefix NMS, top-100, mask + match branches, paste -- against the CPU oracle (ref models/video_matchrcnn.py:154-205,235-314).
 
 Proposals and detections are compared as EXACT sets (same label, coordinates within 0.05 px, scores within 1e-4) up to a
-printed list of at most 5 near-tie flips per side (tests/parity_sets.py); descriptors / ROI features / masks of the paired
-detections within the north_star tolerance (1e-3 of scale)."""
+printed list of at most ONE near-tie flip per side (tests/parity_sets.py: the observed count is 0 on every case, the gate is
+observed + 1); descriptors / ROI features / masks of the paired detections within the north_star tolerance (1e-3 of scale).
+Frames: two synthetic 800x800 seeds and one 1080x1920 frame (resized to 750x1333, padded 768x1344: 257 796 anchors -- the
+geometry of BASELINE configs[4])."""
 import pytest
 import torch
 
@@ -42,7 +44,7 @@ def test_rpn_proposals_800(world):
     partner = assert_same_set(o, p, tol_px=1e-2, what="RPN proposals 800x800")
     # ... and in the same objectness order, flips aside
     ok = partner >= 0
-    assert int((partner[ok] == torch.arange(len(o))[ok]).sum()) >= len(o) - 10
+    assert int((partner[ok] == torch.arange(len(o))[ok]).sum()) >= len(o) - 2
 
 
 def _check_detections(out, ref, what):
@@ -50,12 +52,12 @@ def _check_detections(out, ref, what):
     partner = assert_same_set(ref["boxes"], out["boxes"], ref["labels"], out["labels"], ref["scores"], out["scores"], what=what)
     ok = partner >= 0
     g = partner[ok]
-    assert int(ok.sum()) >= 95
+    assert int(ok.sum()) >= len(ref["scores"]) - 1
     assert_close(out["scores"].cpu()[g], ref["scores"][ok], rtol=1e-4)
     assert_close(out["match_features"].cpu()[g], ref["match_features"][ok], rtol=1e-3, atol_scale=1e-3)
     assert_close(out["roi_features"].cpu()[g], ref["roi_features"][ok], rtol=1e-3, atol_scale=1e-3)
     gm, om = out["masks"].cpu()[g], ref["masks"][ok]
-    assert gm.shape[1:] == (1, 800, 800)
+    assert gm.shape[1:] == om.shape[1:]
     assert float(((gm - om).abs() > 2e-3).float().mean()) < 1e-4           # paste: a box edge 1e-4 px off can move a border pixel
     return partner
 
@@ -124,6 +126,29 @@ def test_box_branch_on_oracle_proposals_800(world):
         res = m.roi_heads.detect(feats, [world["oprops"][0].to(DEV)], sizes)[0]
         ref = OMm.detect(world["ofe"], world["oprops"], world["osz"], world["sd"], 0.1)[0]
     partner = assert_same_set(ref["boxes"], res["boxes"], ref["labels"], res["labels"], ref["scores"], res["scores"], tol_px=1e-2,
-                              max_flips=2, what="box branch on oracle proposals")
+                              what="box branch on oracle proposals")
     ok = partner >= 0
     assert_close(res["scores"].cpu()[partner[ok]], ref["scores"][ok], rtol=1e-4)
+
+
+@pytest.mark.parametrize("seed,h,w,padded_hw", [(302, 800, 800, (800, 800)), (303, 1080, 1920, (768, 1344))])
+def test_drop_in_forward_other_frames(world, seed, h, w, padded_hw):
+    """A second 800x800 seed and a 1080x1920 frame through the real ``model([img])``: proposals (exact set, same order) and
+    detections / descriptors / ROI features / pasted masks against the oracle."""
+    m, sd = world["m"], world["sd"]
+    img = torch.from_numpy(synth.frames(seed, 1, h, w)[0])
+    with torch.no_grad():
+        ofe, osz, opad = OM.extract_features([img], sd)
+        oprops, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
+        ref, _, _ = OM.video_matchrcnn_forward([img], sd)
+        feats, sizes, orig, padded = m.extract_features([img.to(DEV)])
+        p = m.rpn(feats, sizes, padded)[0].cpu()
+        out = m([img.to(DEV)])[0]
+    assert tuple(padded) == padded_hw == tuple(opad)
+    o = oprops[0]
+    assert len(o) == len(p)
+    partner = assert_same_set(o, p, tol_px=1e-2, what=f"RPN proposals {h}x{w} seed {seed}")
+    ok = partner >= 0
+    assert int((partner[ok] == torch.arange(len(o))[ok]).sum()) >= len(o) - 2
+    assert len(ref[0]["scores"]) == len(out["scores"])
+    _check_detections(out, ref[0], f"detections {h}x{w} seed {seed}")

@@ -212,7 +212,7 @@ def test_full_forward_with_rpn(model_and_state):
         assert set(o) >= {"boxes", "labels", "scores", "masks", "match_features", "w", "b", "roi_features"}
         # detections are a discrete selection (top-k / NMS): exact as a set up to a printed, bounded list of near-tie flips
         from parity_sets import assert_same_set
-        partner = assert_same_set(r["boxes"], o["boxes"], r["labels"], o["labels"], r["scores"], o["scores"], max_flips=5,
+        partner = assert_same_set(r["boxes"], o["boxes"], r["labels"], o["labels"], r["scores"], o["scores"], max_flips=2,
                                   what="full forward 192x256")
         ok = partner >= 0
         assert_close(o["scores"].cpu()[partner[ok]], r["scores"][ok], rtol=1e-4)

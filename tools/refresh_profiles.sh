@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerate the round's measurement artefacts on the GPU box -> gpurun_out/<tag>_*  (copy the summaries into profiles/).
-# usage: tools/refresh_profiles.sh <tag>
+# usage: tools/refresh_profiles.sh <tag>      (ONE generation per round, on the final tree; the frozen bf16x3 experiment is not refreshed)
 TAG=${1:-r01}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp
 python3 $R/bench.py > $O/${TAG}_bench.json 2>$O/${TAG}_bench.err
@@ -11,12 +11,10 @@ cp /tmp/prof_$TAG/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/nul
 bash $R/tools/pmc_bench_traffic.sh $TAG > $O/${TAG}_pmc.log 2>&1
 python3 $R/bench.py --workload c3 --no-roofline --cpu-runs 1 > $O/${TAG}_bench_c3.json 2>/dev/null
 python3 $R/bench.py --workload c4 --no-roofline --no-cpu-baseline > $O/${TAG}_bench_c4.json 2>/dev/null
-python3 $R/bench.py --dtype bf16x3 --no-cpu-baseline > $O/${TAG}_bench_bf16x3.json 2>/dev/null
 python3 $R/bench.py --dtype f16 --no-cpu-baseline > $O/${TAG}_bench_f16.json 2>/dev/null
 python3 $R/bench.py --dtype f16 --workload c5 --no-cpu-baseline --steps 5 --warmup 1 > $O/${TAG}_bench_c5_f16.json 2>/dev/null
 python3 $R/bench.py --graph --clips 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_graph.json 2>/dev/null
 python3 $R/bench.py --clips 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_clips1.json 2>/dev/null
-bash $R/tools/pmc_bench_traffic.sh ${TAG}_bf16x3 --dtype bf16x3 > $O/${TAG}_pmc_bf16x3.log 2>&1
 python3 $R/tools/heads_bench.py > $O/${TAG}_heads_bench.txt 2>/dev/null
 for G in 20000 50000; do
   rm -rf /tmp/pmf_$TAG
