@@ -285,6 +285,9 @@ int seam_rank_of_f32(const float* logits, const int64_t* target, int64_t* rank, 
  * order of the plain score row q of [Q,G] (ties -> lower index first; what `np.argsort(x)[::-1] ==
  * shop_prod_index` extracts at :296-297,306-307). */
 int seam_score_reduce_f32(const float* score, float* out, int n, int G, int mode, seam_stream_t stream);
+/* ... over row segments: rows seg[p] .. seg[p+1]-1 (seg: P+1 int32 offsets on the device) -> out [P,G], one launch for all
+ * products of an evaluator pass; bit-identical to P calls of seam_score_reduce_f32 (P <= 65535). */
+int seam_score_reduce_seg_f32(const float* score, const int* seg, float* out, int P, int G, int mode, seam_stream_t stream);
 int seam_rank_of_scores_f32(const float* score, const int64_t* target, int64_t* rank, int Q, int G,
                             seam_stream_t stream);
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     "seam_match_scores_f32": (_i, [_p, _p, _i64, _p]),
     "seam_rank_of_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_score_reduce_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    "seam_score_reduce_seg_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "seam_rank_of_scores_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_box_iou_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_pair_topk_workspace_floats": (_i64, [_i, _i, _i]),

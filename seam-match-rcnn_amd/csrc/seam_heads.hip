@@ -698,6 +698,21 @@ __global__ void score_reduce_kernel(const float* __restrict__ s, float* __restri
     out[g] = mode ? acc : acc / (float)n;
 }
 
+// The same reduction over row SEGMENTS: rows seg[p] .. seg[p+1]-1 -> out[p, :] (one launch for all products of an evaluator pass;
+// per column the rows are visited in the same order as score_reduce_kernel visits them: bit-identical to per-segment calls)
+__global__ void score_reduce_seg_kernel(const float* __restrict__ s, const int* __restrict__ seg, float* __restrict__ out, int G, int mode) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = blockIdx.y;
+    if (g >= G) return;
+    const int lo = seg[p], hi = seg[p + 1];
+    float acc = mode ? -INFINITY : 0.f;
+    for (int i = lo; i < hi; ++i) {
+        const float v = s[(size_t)i * G + g];
+        acc = mode ? fmaxf(acc, v) : acc + v;
+    }
+    out[(size_t)p * G + g] = mode ? acc : acc / (float)(hi - lo);
+}
+
 // rank of target[q] in the descending order of a plain score row (ties -> lower index first)
 __global__ __launch_bounds__(256) void rank_of_scores_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
                                                              int64_t* __restrict__ rank, int G) {
@@ -792,6 +807,13 @@ int seam_score_reduce_f32(const float* score, float* out, int n, int G, int mode
     if (G <= 0) return 0;
     if (n <= 0 || mode < 0 || mode > 1) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(score_reduce_kernel, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, score, out, n, G, mode);
+    return (int)hipGetLastError();
+}
+
+int seam_score_reduce_seg_f32(const float* score, const int* seg, float* out, int P, int G, int mode, void* stream) {
+    if (G <= 0 || P <= 0) return 0;
+    if (mode < 0 || mode > 1 || P > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(score_reduce_seg_kernel, dim3((G + 255) / 256, P), dim3(256), 0, (hipStream_t)stream, score, seg, out, G, mode);
     return (int)hipGetLastError();
 }
 

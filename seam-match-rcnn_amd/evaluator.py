@@ -212,8 +212,161 @@ _TABLES = ("frame", "max_per_image", "aggr_desc", "avg_desc", "avg_dist", "max_d
 
 @torch.no_grad()
 def evaluate_tables(t: DescriptorTables, temporal_aggregator, k_thresholds: Sequence[int] = K_THRESHOLDS,
+                    frames_per_product: int = 3, tracking_threshold: float = 0.3, max_dets_per_pass: int = 2048,
+                    max_pairs_per_pass: int = 1 << 25) -> RetrievalReport:
+    """evaluate_movingfashion.py:123-334 on device-resident tables, BATCHED over products: every stage is one launch over all
+    products of a pass (self-similarity, tracklet IoUs, per-frame ranks, AVG DESC, AVG / MAX DISTANCE, AGGR DESC as Mode B with
+    S = #products) and one device -> host copy; only the greedy tracklet linking (a few dozen boxes per product) runs per
+    product, on the host.  A pass takes as many products as fit ``max_dets_per_pass`` detections (the self-similarity stage
+    computes their all-pairs matrix and keeps its diagonal blocks) and ``max_pairs_per_pass`` (query, shop) pairs.
+    Same arithmetic per product as ``evaluate_tables_per_product`` (the kernels work row by row / segment by segment):
+    identical reports, tested."""
+    ks = np.asarray(k_thresholds)
+    rep = RetrievalReport(k_thresholds=tuple(k_thresholds), count_street=t.count_street, frames_per_product=frames_per_product)
+    for name in _TABLES:
+        for sub in ("", "_reg", "_hard"):
+            rep.counts[name + sub] = np.zeros(len(ks), dtype=np.int64)
+    dev = t.shop_mat.device
+    aggr_w, aggr_b = temporal_aggregator.last.weight.detach(), temporal_aggregator.last.bias.detach()
+    G = t.shop_mat.shape[0]
+
+    def hit(name, rank, sub):
+        h = (rank < ks).astype(np.int64)
+        rep.counts[name] += h
+        if name != "max_per_image":
+            rep.counts[name + sub] += h
+        return h
+
+    # products in order, with their shop entry and their detections (ascending street index, as np.flatnonzero gives them)
+    first_shop = {}
+    for i, pr in enumerate(t.shop_prods.tolist()):
+        first_shop.setdefault(pr, i)
+    order = np.argsort(t.street_prods, kind="stable")
+    sp_sorted = t.street_prods[order]
+    todo = []
+    for p in range(t.count_street):
+        if p not in first_shop:
+            continue
+        lo, hi = np.searchsorted(sp_sorted, p, "left"), np.searchsorted(sp_sorted, p, "right")
+        todo.append((p, first_shop[p], order[lo:hi]))
+
+    def idx(a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int64, device=dev)
+
+    pos = 0
+    while pos < len(todo):
+        # ---- the products of this pass
+        batch, ndet = [], 0
+        while pos < len(todo) and (not batch or (ndet + len(todo[pos][2]) <= max_dets_per_pass
+                                                  and (ndet + len(todo[pos][2])) * max(G, 1) <= max_pairs_per_pass)):
+            batch.append(todo[pos])
+            ndet += len(todo[pos][2])
+            pos += 1
+        offs = np.cumsum([0] + [len(d) for _, _, d in batch])
+        dets_all = np.concatenate([d for _, _, d in batch]) if ndet else np.zeros((0,), dtype=np.int64)
+        dets_d = idx(dets_all)
+        mine_all = t.street_mat[dets_d]
+
+        # ---- tracking (:166-214): all-pairs similarity of the pass's detections, its diagonal blocks to the host (copy 1)
+        sim_full = ops.match_scores(ops.pair_logits(mine_all, mine_all, t.w, t.b))
+        flat = np.concatenate([((o + np.arange(n))[:, None] * ndet + (o + np.arange(n))[None, :]).reshape(-1)
+                               for o, n in zip(offs[:-1], np.diff(offs))]) if ndet else np.zeros((0,), dtype=np.int64)
+        blocks = sim_full.view(-1)[idx(flat)].cpu().numpy()
+        del sim_full
+        tracks_all, bo = [], 0
+        for (p, _, dets), o in zip(batch, offs[:-1]):
+            n = len(dets)
+            simmat = blocks[bo:bo + n * n].reshape(n, n)
+            bo += n * n
+            tracks_all.append(build_tracklets(simmat, t.street_imgs[dets], t.street_scores[dets], tracking_threshold))
+        # IoU of every tracklet member with the ground truth of every member's frame (copy 2); the reference indexes the GT list
+        # by the frame index inside the clip (:205)
+        imgs_all = t.street_imgs[dets_all]
+        n_gt = int(imgs_all.max()) + 1 if ndet else 0
+        iou_full = ops.box_iou(t.street_boxes[dets_d].contiguous(), t.tracklets_gt[:n_gt].contiguous())      # [ndet, n_gt]
+        rows, cols, shapes = [], [], []
+        for (p, _, dets), o, tracks in zip(batch, offs[:-1], tracks_all):
+            im = t.street_imgs[dets]
+            for members in tracks:
+                mm = np.asarray(members)
+                rows.append(np.repeat(o + mm, len(mm)))
+                cols.append(np.tile(im[mm], len(mm)))
+                shapes.append(len(mm))
+        vals = iou_full[idx(np.concatenate(rows)), idx(np.concatenate(cols))].cpu().numpy()
+        chosen, vo, ti = [], 0, 0
+        for (p, _, dets), tracks in zip(batch, tracks_all):
+            best, best_iou = 0, -np.inf
+            for k, members in enumerate(tracks):
+                m = shapes[ti]
+                iou = float(vals[vo:vo + m * m].reshape(m, m).max(-1).sum())
+                vo += m * m
+                ti += 1
+                if iou > best_iou:
+                    best, best_iou = k, iou
+            members = np.asarray(tracks[best])
+            chosen.append(members[np.argsort(t.street_imgs[dets][members], kind="stable")])    # frames in unique_imgs order (:225)
+
+        # ---- one query per tracked frame of every product (:225-239), all products at once
+        seg = np.cumsum([0] + [len(m) for m in chosen])
+        P, Q = len(batch), int(seg[-1])
+        q_local = np.concatenate([o + m for o, m in zip(offs[:-1], chosen)])               # rows of mine_all
+        q_d = idx(q_local)
+        shop_idx = np.asarray([si for _, si, _ in batch])
+        target_p = idx(shop_idx)
+        target_q = idx(np.repeat(shop_idx, np.diff(seg)))
+        queries = mine_all[q_d].contiguous()
+        logits = ops.pair_logits(queries, t.shop_mat, t.w, t.b)
+        frame_rank_d = ops.rank_of(logits, target_q)
+        distances = ops.match_scores(logits)                                             # [Q, G]
+        del logits
+        seg_d = torch.as_tensor(seg, dtype=torch.int32, device=dev)
+        # AVG DESC (:279-291), AVG & MAX DISTANCE (:293-315): segment reductions, then one rank launch each
+        avg_rank_d = ops.rank_of(ops.pair_logits(ops.score_reduce_segments(queries, seg_d, "mean"), t.shop_mat, t.w, t.b), target_p)
+        both = torch.cat([ops.score_reduce_segments(distances, seg_d, "mean"), ops.score_reduce_segments(distances, seg_d, "max")])
+        dist_rank_d = ops.rank_of_scores(both, target_p.repeat(2))
+        # AGGR DESC (:250-276): Mode B over the tracked frames' aggregator descriptors, S = #products sequences
+        tmax = int(np.diff(seg).max())
+        seq = torch.zeros((1 + tmax, P, t.street_aggr.shape[1]), device=dev)
+        trow = np.concatenate([1 + np.arange(len(m)) for m in chosen])
+        tcol = np.repeat(np.arange(P), np.diff(seg))
+        seq[idx(trow), idx(tcol)] = t.street_aggr[dets_d[q_d]]
+        mask = torch.as_tensor(np.arange(1 + tmax)[None, :] > np.diff(seg)[:, None], device=dev)
+        desc = temporal_aggregator(None, None, None, x3_1_seq=seq, x3_1_mask=mask, x3_2=t.shop_aggr[:1])[0][:P]
+        aggr_rank_d = ops.rank_of(ops.pair_logits(desc.contiguous(), t.shop_aggr, aggr_w, aggr_b), target_p)
+        ranks = torch.cat([frame_rank_d, avg_rank_d, dist_rank_d, aggr_rank_d]).cpu().numpy()      # copy 3
+        frame_rank_all, avg_rank = ranks[:Q], ranks[Q:Q + P]
+        dist_rank, aggr_rank = ranks[Q + P:Q + 3 * P], ranks[Q + 3 * P:]
+
+        # ---- the counters, product by product in the reference's order
+        for j, ((p, shop_index, dets), members) in enumerate(zip(batch, chosen)):
+            sub = "_reg" if t.shop_sources[shop_index] == 1 else "_hard"
+            if sub == "_reg":
+                rep.count_reg += 1
+            else:
+                rep.count_hard += 1
+            rep.track_lens.append(len(members))
+            frame_rank = frame_rank_all[seg[j]:seg[j + 1]]
+            per = {"sfmr": np.zeros(len(ks)), "seamrcnn": np.zeros(len(ks))}
+            for r in frame_rank:
+                per["sfmr"] += hit("frame", r, sub)
+            rep.frame_ranks += [int(r) for r in frame_rank]
+            hit("max_per_image", frame_rank.min(), sub)                              # (:243-247)
+            per["seamrcnn"] += hit("aggr_desc", int(aggr_rank[j]), sub)
+            hit("avg_desc", int(avg_rank[j]), sub)
+            hit("avg_dist", int(dist_rank[j]), sub)
+            hit("max_dist", int(dist_rank[P + j]), sub)
+            hit("max_score", int(frame_rank[int(np.argmax(t.street_scores[dets][members]))]), sub)   # (:317-328)
+            key = t.product_keys[shop_index] if t.product_keys is not None else shop_index
+            rep.per_product[key] = {"sfmr": per["sfmr"] / frames_per_product, "seamrcnn": per["seamrcnn"] / 1.0}
+    return rep
+
+
+@torch.no_grad()
+def evaluate_tables_per_product(t: DescriptorTables, temporal_aggregator, k_thresholds: Sequence[int] = K_THRESHOLDS,
                     frames_per_product: int = 3, tracking_threshold: float = 0.3) -> RetrievalReport:
-    """evaluate_movingfashion.py:123-334 on device-resident tables."""
+    """evaluate_movingfashion.py:123-334 on device-resident tables, ONE PRODUCT AT A TIME (seven device -> host copies per
+    product: the round-2 form, sync-bound at ~1 ms per product).  Kept as the reference the batched ``evaluate_tables`` is tested
+    against: both must produce identical reports."""
     ks = np.asarray(k_thresholds)
     rep = RetrievalReport(k_thresholds=tuple(k_thresholds), count_street=t.count_street, frames_per_product=frames_per_product)
     for name in _TABLES:

@@ -859,6 +859,19 @@ def score_reduce(score: torch.Tensor, mode: str) -> torch.Tensor:
     return out
 
 
+def score_reduce_segments(score: torch.Tensor, seg: torch.Tensor, mode: str) -> torch.Tensor:
+    """score [N,G], seg [P+1] int32 row offsets (device) -> [P,G]: ``score_reduce`` of the rows seg[p]:seg[p+1] of every segment in
+    ONE launch (the same sequential row order per column: bit-identical to P separate calls)."""
+    score = _req(score)
+    seg = _req(seg, torch.int32, "seg")
+    n, g = score.shape
+    p = seg.numel() - 1
+    out = torch.empty((p, g), dtype=F32, device=score.device)
+    _native.check(_native.lib().seam_score_reduce_seg_f32(_ptr(score), _ptr(seg), _ptr(out), p, g, {"mean": 0, "max": 1}[mode], _stream()),
+                  "seam_score_reduce_seg_f32")
+    return out
+
+
 def rank_of_scores(score: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """score [Q,G], target int64 [Q] -> rank int64 [Q] of the target in each row's descending order."""
     score, target = _req(score), _req(target, torch.int64, "target")

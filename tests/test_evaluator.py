@@ -217,6 +217,52 @@ def test_device_tables_vs_oracle(seed, noise):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_dets", [2048, 25])
+def test_batched_tables_equal_the_per_product_form(max_dets):
+    """evaluate_tables (one launch per stage over all products of a pass, three device -> host copies per pass) against
+    evaluate_tables_per_product (seven copies per product): identical reports -- in ONE pass and cut into many small passes."""
+    from seam_match_rcnn_amd import evaluator as EV
+    from seam_match_rcnn_amd.models.match_head import TemporalAggregationNLB
+    dev = torch.device("cuda:0")
+    tab = make_tables(6, noise=0.8)
+    agg_sd = to_torch(synth.temporal_aggregator_state(12))
+    ta = TemporalAggregationNLB()
+    ta.load_state_dict(agg_sd)
+    ta = ta.to(dev).eval()
+    d = lambda k: torch.from_numpy(tab[k]).to(dev)
+    t = EV.DescriptorTables(shop_mat=d("shop_mat"), shop_aggr=d("shop_aggr"), shop_prods=tab["shop_prods"], shop_sources=tab["shop_sources"],
+                            street_mat=d("street_mat"), street_aggr=d("street_aggr"), street_prods=tab["street_prods"],
+                            street_imgs=tab["street_imgs"], street_scores=tab["street_scores"], street_boxes=d("street_boxes"),
+                            tracklets_gt=d("tracklets_gt"), w=d("w"), b=d("b"), count_street=tab["count_street"])
+    a = EV.evaluate_tables(t, ta, max_dets_per_pass=max_dets)
+    b = EV.evaluate_tables_per_product(t, ta)
+    assert a.track_lens == b.track_lens and a.frame_ranks == b.frame_ranks
+    assert (a.count_reg, a.count_hard) == (b.count_reg, b.count_hard)
+    assert a.counts.keys() == b.counts.keys()
+    for k in a.counts:
+        assert (a.counts[k] == b.counts[k]).all(), k
+    assert a.per_product.keys() == b.per_product.keys()
+    for k in a.per_product:
+        for kk in ("sfmr", "seamrcnn"):
+            assert (a.per_product[k][kk] == b.per_product[k][kk]).all()
+    assert a.tables_text() == b.tables_text()
+
+
+@pytest.mark.gpu
+def test_score_reduce_segments_equals_per_segment_calls():
+    from seam_match_rcnn_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1)
+    s = torch.from_numpy(rng.standard_normal((23, 777)).astype(np.float32)).to(dev)
+    seg = [0, 1, 4, 4 + 10, 23]
+    sd = torch.tensor(seg, dtype=torch.int32, device=dev)
+    for mode in ("mean", "max"):
+        got = ops.score_reduce_segments(s, sd, mode)
+        for p in range(len(seg) - 1):
+            assert torch.equal(got[p], ops.score_reduce(s[seg[p]:seg[p + 1]].contiguous(), mode)), (mode, p)
+
+
+@pytest.mark.gpu
 def test_score_reduce_rank_of_scores_box_iou():
     from seam_match_rcnn_amd import ops
     dev = torch.device("cuda:0")

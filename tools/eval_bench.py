@@ -31,6 +31,12 @@ torch.cuda.synchronize(); gpu = time.perf_counter() - t0
 t0 = time.perf_counter()
 ref = OE.evaluate_tables(tab, sd, frames_per_product=Fr)
 cpu = time.perf_counter() - t0
+EV.evaluate_tables_per_product(t, ta, frames_per_product=Fr)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+rep1 = EV.evaluate_tables_per_product(t, ta, frames_per_product=Fr)
+torch.cuda.synchronize(); gpu1 = time.perf_counter() - t0
+print(f"per-product form (round 2-3): {gpu1*1e3:.0f} ms ({gpu1/P*1e3:.2f} ms/product); batched form: {gpu*1e3:.0f} ms ({gpu/P*1e3:.3f} ms/product); "
+      f"identical reports: {rep1.tables_text() == rep.tables_text() and rep1.frame_ranks == rep.frame_ranks}")
 same = all((rep.counts[k] == ref[k]).all() for k in rep.counts)
 print(f"{P} products x {Fr} frames ({len(tab['street_prods'])} street boxes) vs {G} shop entries: device {gpu*1e3:.0f} ms "
       f"({gpu/P*1e3:.2f} ms/product), NumPy oracle (fp32, {os.cpu_count()} cores visible) {cpu*1e3:.0f} ms ({cpu/P*1e3:.2f} ms/product), "
