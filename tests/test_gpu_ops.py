@@ -643,3 +643,51 @@ def test_rpn_topk_decode_matches_sort_and_oracle(ops):
             assert_close(sc[i, 5:5 + k], torch.sigmoid(obj[i][top[i]]), rtol=1e-5, atol_scale=1e-6)
     with pytest.raises(ValueError):
         ops.rpn_topk_decode(hd, a, anc.to(d), clip.to(d), 1025, bx, sc, 0)
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 72, 256, 128), (2, 48, 72, 256, 256), (3, 40, 56, 64, 256), (1, 14, 14, 256, 1024),
+                                   (5, 33, 31, 128, 512), (2, 20, 20, 256, 64), (4, 50, 50, 64, 64)])
+def test_pointwise_weights_stationary_kernel(ops, shape):
+    """seam_conv1x1_sw_f32 (csrc/seam_pw.hip) on ragged maps, every epilogue mode -- none / ReLU / residual + ReLU / FPN top-down
+    merge / two-source reduction -- against the torch reference (1e-3 contract) and against the implicit GEMM on the same inputs
+    (two exact-fp32 chains: <= 2e-5 of scale apart); five repetitions of every launch must be bit-identical (the kernel has no
+    barriers after its prologue: a race would show as run-to-run differences)."""
+    d = dev()
+    n, h, w, c, k = shape
+    x, res = rnd(90, (n, c, h, w)), rnd(91, (n, k, h, w))
+    top = rnd(92, (n, k, (h + 1) // 2, (w + 1) // 2))
+    wgt = rnd(93, (k, c, 1, 1), "w") / (c ** 0.5)
+    bn = (torch.from_numpy(synth.uniform(synth.stream_id(94, "bw"), (k,), 0.5, 1.5)), rnd(95, (k,), "bb") * 0.1,
+          rnd(96, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(97, "rv"), (k,), 0.5, 1.5)))
+    sc = bn[0] * (bn[3] + 1e-5).rsqrt()
+    conv = F.conv2d(x, wgt) * sc[None, :, None, None] + (bn[1] - bn[2] * sc)[None, :, None, None]
+    pc = ops.pack_conv(wgt.to(d), None, tuple(t.to(d) for t in bn))
+    assert pc.ws is not None and h * w >= ops.SW_MIN_HW
+    bias = rnd(98, (k,), "b")
+    pcb = ops.pack_conv(wgt.to(d), bias.to(d))
+    xd, rd, td = nhwc(x).to(d), nhwc(res).to(d), nhwc(top).to(d)
+    cases = [("plain", lambda: ops.conv2d(xd, pc), conv),
+             ("relu", lambda: ops.conv2d(xd, pc, relu=True), F.relu(conv)),
+             ("residual", lambda: ops.conv2d(xd, pc, relu=True, residual=rd), F.relu(conv + res)),
+             ("topdown", lambda: ops.conv2d_topdown(xd, pcb, td),
+              F.conv2d(x, wgt, bias) + F.interpolate(top, size=(h, w), mode="nearest"))]
+    if c % 64 == 0:
+        c1 = c // 2
+        pcd = ops.pack_conv_dual(wgt[:, :c1].to(d), tuple(t.to(d) for t in bn), wgt[:, c1:].to(d), tuple(t.to(d) for t in bn))
+        xa, xb = nhwc(x[:, :c1]).contiguous().to(d), nhwc(x[:, c1:]).contiguous().to(d)
+        sh2 = 2 * (bn[1] - bn[2] * sc)
+        cases.append(("dual", lambda: ops.conv2d_dual(xa, xb, pcd, 1, relu=True),
+                      F.relu(F.conv2d(x, wgt) * sc[None, :, None, None] + sh2[None, :, None, None])))
+    saved = ops.SW
+    try:
+        for name, run, ref in cases:
+            ops.SW = True
+            got = run()
+            assert_close(got.permute(0, 3, 1, 2), ref)
+            for _ in range(4):
+                assert torch.equal(run(), got), name
+            ops.SW = False
+            other = run()
+            assert float((got - other).abs().max()) <= 2e-5 * float(other.abs().max()), name
+    finally:
+        ops.SW = saved
