@@ -123,9 +123,10 @@ def needs_self_launch(gpus, env):
 
 
 def self_launch(args, argv=None, popen=None):
-    """Start N ranks as a CHILD `python -m torch.distributed.run ... bench.py <same flags>` (subprocess, never exec; nothing in this
-    process has touched HIP yet -- torch.cuda.device_count() does not initialise the runtime), relay rank 0's single JSON line on
-    this process's stdout, everything else on stderr, and return the child's exit code.  `popen` is a test seam."""
+    """Start N ranks as a CHILD `python -m torch.distributed.run ... bench.py <same flags>`, relay rank 0's single JSON line on this
+    process's stdout, everything else on stderr, and return the child's exit code.  ALWAYS a subprocess, never an exec: counting the
+    GPUs below may already have initialised HIP in this parent (on ROCm builds without amdsmi torch.cuda.device_count() falls back to
+    hipGetDeviceCount), and replacing a process that has touched the GPU takes the machine down on this pool.  `popen` is a test seam."""
     import subprocess
     argv = sys.argv[1:] if argv is None else argv
     if popen is None:
@@ -593,13 +594,15 @@ def roofline_leg(step, dtype):
 
 
 def csrc_digest():
-    """Identity of the convolution kernels' sources (the kernels the roofline leg reports): sha256 over the three files that define
-    them (name + bytes)."""
+    """Identity of the kernel sources a committed counter file was collected on: sha256 over EVERY csrc/*.hip and csrc/*.h file
+    (name + bytes, sorted) -- a stale counter file is then never reported as current for any kernel of the library."""
+    import glob
     import hashlib
     h = hashlib.sha256()
-    for name in ("seam_conv.hip", "seam_wino.hip", "seam_wino24.hip"):
-        h.update(name.encode())
-        h.update(open(os.path.join(ROOT, "seam-match-rcnn_amd", "csrc", name), "rb").read())
+    d = os.path.join(ROOT, "seam-match-rcnn_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 
 

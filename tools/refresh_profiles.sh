@@ -22,5 +22,10 @@ for G in 20000 50000; do
   (cat /tmp/pmf_$TAG/p_kernel_stats.csv 2>/dev/null || cat /tmp/pmf_$TAG/*/p_kernel_stats.csv) > $O/${TAG}_pairmf_${G}_kernel_stats.csv
 done
 python3 $R/tools/train_bench.py 8 10 > $O/${TAG}_train_bench.txt 2>/dev/null
+python3 $R/tools/eval_bench.py 200 2000 10 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_eval_bench.txt
+python3 $R/tools/eval_bench.py 200 20000 10 2>/dev/null | grep -v amdgpu.ids >> $O/${TAG}_eval_bench.txt
+python3 $R/tools/conv_breakdown.py 8 f32 c2 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_breakdown_f32.txt
+python3 $R/tools/conv_breakdown.py 8 f16 c5 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_breakdown_c5_f16.txt
+python3 $R/bench.py --workload c4 --force-collective --no-roofline --no-cpu-baseline --no-extras > $O/${TAG}_bench_c4_one_rank_rccl.json 2>/dev/null
 python3 $R/tools/full_forward_timing.py > $O/${TAG}_full_forward.txt 2>/dev/null
 ls -la $O | grep $TAG
