@@ -73,6 +73,11 @@ class _NonLocalBlockND(nn.Module):
         """x: (b, 256, t) -> z: (b, 256, t)      (ref models/nlb.py:66-101)"""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             # grad-enabled direct call: the same forward kernel with the block's own backward behind it (t <= 64)
+            if x.shape[-1] > 64:
+                # fail here, not later inside backward() (seam_nlb_block_bwd_f32 keeps a sequence in LDS: hipErrorInvalidValue);
+                # inference on longer sequences: call under torch.no_grad()
+                raise NotImplementedError(f"NONLocalBlock1D: grad-enabled pass supports sequences of <= 64 frames, got {x.shape[-1]}; "
+                                          "wrap inference calls in torch.no_grad()")
             from ..autograd import NlbBlockFunction
             return NlbBlockFunction.apply(x, self.theta.weight, self.theta.bias, self.phi.weight, self.phi.bias, self.g.weight,
                                           self.g.bias, self.concat_project[0].weight, self.W.weight, self.W.bias)

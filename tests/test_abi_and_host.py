@@ -183,3 +183,14 @@ def test_state_dict_keys_and_both_torchvision_layouts():
     assert not any("temporal_aggregator" in k for k in m1.state_dict())
     with pytest.raises(NotImplementedError):
         m.train()([torch.zeros(3, 32, 32)])
+
+
+def test_grad_enabled_nlb_rejects_long_sequences_up_front():
+    """A grad-enabled direct call of the non-local block on more than 64 frames fails in forward() with a clear message (the
+    backward kernel keeps a sequence in LDS and would only fail inside backward())."""
+    import pytest
+    import torch
+    from seam_match_rcnn_amd.models.nlb import NONLocalBlock1D
+    blk = NONLocalBlock1D(256, sub_sample=False, bn_layer=False)
+    with pytest.raises(NotImplementedError, match="<= 64 frames"):
+        blk(torch.zeros(1, 256, 65, requires_grad=True))
