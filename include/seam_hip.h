@@ -428,6 +428,7 @@ int seam_linear_narrow_f32(const float* x, const float* w_packed, const float* b
 long long seam_wino24_weight_floats(int K, int Cstore);
 long long seam_wino24_issue_slots(int N, int H, int W, int C, int K, int pad);
 int seam_wino24_variant(int N, int H, int W, int C, int K, int pad);   /* n-tiles per block (kernel variant conv3x3_wino24<NT>) picked for this shape; 0 = unsupported */
+int seam_wino24_form(int N, int H, int W, int C, int K, int pad);      /* 1: the launch runs on the producer / consumer kernel conv3x3_wino24pc (round 5: the NT = 2 block as four MFMA-only waves + four transform / load waves, two per SIMD; bit-identical results), 0: conv3x3_wino24<NT>, -1: unsupported.  SEAM_W24_PC=0 in the environment keeps every launch on conv3x3_wino24<NT> */
 long long seam_wino_issue_slots(int N, int H, int W, int C, int K, int pad);
 int seam_pack_conv_weight_wino24_f32(const float* w, float* u_packed, int K, int Cin, int Cstore, int mode,
                                      seam_stream_t stream);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "seam_wino_issue_slots": (C.c_longlong, [_i, _i, _i, _i, _i, _i]),
     "seam_wino24_issue_slots": (C.c_longlong, [_i, _i, _i, _i, _i, _i]),
     "seam_wino24_variant": (_i, [_i, _i, _i, _i, _i, _i]),
+    "seam_wino24_form": (_i, [_i, _i, _i, _i, _i, _i]),
     "seam_wino24_weight_floats": (C.c_longlong, [_i, _i]),
     "seam_pack_conv_weight_wino24_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "seam_conv3x3_wino24_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <atomic>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -153,6 +155,7 @@ struct Wino24Args {
     // patches (tm) cut into 8 / nsplit partitions of part_q (+1 for the first part_r) each
     int nsplit, tns, part_q, part_r;
     unsigned m_tns;
+    unsigned long long* trace;   // SEAM_W24PC_TRACE builds only: s_memtime stamps of one block's waves 0 and 4 (else null)
 };
 
 // a / d for 0 <= a, a * d < 2^32, with m = ceil(2^32 / d) (d >= 2) -- one v_mul_hi_u32 / s_mul_hi_u32
@@ -637,6 +640,435 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
     else w24_block<NT, 0>(p, smem, reg, rb, tm, tn, tm_img);
 }
 
+// =====================================================================================================================
+// conv3x3_wino24pc (round 5): the NT = 2 block as a PRODUCER / CONSUMER pair of wave groups -- two waves per SIMD.
+//
+// What round 4 measured on conv3x3_wino24<2>: the block is alone on its CU (one wave per SIMD, 490 registers), and within ONE
+// wave nothing vector-ALU overlaps an fp32 MFMA -- the input transform (36 packed ops), the patch loads / LDS stores and the
+// waits behind them cost ~17 % of every chunk -- while ANOTHER wave of the same SIMD runs VALU / LDS / memory instructions
+// beside an MFMA-streaming wave for free (tools/mfma_shadow_probe.hip).  So the work is split by role:
+//   waves 0..3 (consumers, one per SIMD): MFMAs only.  Wave xi owns the positions (xi, nu = 0..5) x 32 tiles x 64 channels
+//     (192 accumulators, all arch VGPRs: with 512 threads per block the budget is 256 registers and hipcc selects the VGPR
+//     form of the MFMA, no AccVGPRs).  Its A fragments come from LDS (`ds_read_b128`, one position ahead), its B fragments
+//     straight from global memory through a small register ring (RING positions x 8 registers, refilled right behind the
+//     MFMAs that read them); its K loop holds no vector-ALU instruction at all.
+//   waves 4..7 (producers, the SIMD partners of 0..3): load the raw patch two chunks ahead (registers -> LDS), compute the
+//     input transform of chunk t + 1 while the consumers multiply chunk t, and write the A fragments to LDS in MFMA layout
+//     V[buf][xi][nu][lane][16 B] (the lane that computes a fragment element is the lane that consumes it: conflict-free
+//     1-KiB rows both ways).
+//   One s_barrier per chunk, placed in the consumer between positions 4 and 5: by then it holds the last fragment of chunk t
+//     in registers, so the producers may overwrite V[t & 1] with chunk t + 2 while the consumer requests chunk t + 1's first
+//     fragment under the eight MFMAs of position 5 -- the LDS latency never faces the matrix pipe.
+// The arithmetic (transform expressions, accumulation order, epilogue) is that of conv3x3_wino24<2>: results are bit-identical.
+// =====================================================================================================================
+#ifndef SEAM_W24PC_ABL
+#define SEAM_W24PC_ABL 0    // experiments: 1 no in-loop patch loads / stores, 2 no in-loop weight loads, 4 no in-loop barrier, 8 no in-loop transforms, 16 no epilogue
+#endif
+constexpr int PC_VB = 4 * 6 * 64 * 16;                 // bytes per V buffer
+constexpr int PC_RAW = 0, PC_V = 2 * RAWB;             // LDS map: raw[2] | V[2]   (the epilogue's exchange array aliases all of it)
+constexpr int PC_EXB = 4 * 4 * 32 * 32 * 4;
+constexpr int PC_LDS = (2 * RAWB + 2 * PC_VB) > PC_EXB ? (2 * RAWB + 2 * PC_VB) : PC_EXB;
+static_assert((2 * RAWB) % 16 == 0, "V buffers are 16-byte aligned");
+
+#define PC_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef SEAM_W24PC_TRACE      // debug: stamp (tag << 56 | s_memtime) into p.trace[wave * 4096 + k++] from lane 0 of the traced block
+#define PC_TR(tag) do { if (tr_on) { const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && tr_k < 4096) p.trace[wave * 4096 + tr_k] = tm_ | ((unsigned long long)(tag) << 56); ++tr_k; } } while (0)
+#else
+#define PC_TR(tag) do { } while (0)
+#endif
+
+template <int HSC, int RING>
+__device__ __forceinline__ void w24pc_block(const Wino24Args& p, char* smem, const int reg, const int rb, const int tm, const int tn,
+                                            const int tm_img) {
+    constexpr int NT = 2;
+    char (*raw)[RAWB] = reinterpret_cast<char (*)[RAWB]>(smem + PC_RAW);
+    float* const ex = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int xi = wave & 3;
+    const int TX = p.TX[reg], TY = p.TY[reg];
+    const int byi = fdiv(rb, p.bx[reg], p.m_bx[reg]);
+    const int bxi = rb - byi * p.bx[reg];
+    const int tys = p.tiles_y, pitch = 2 * tys + 2;
+    const int R0 = tm * TY;
+    const int n_img = p.stack ? fdiv(R0, tys, p.m_tys) : tm_img;
+    const int prow0 = p.stack ? 2 * (R0 - n_img * tys) : 0;
+    const int n_here = min(p.G, p.N - n_img);
+    const int ty0 = p.stack ? 0 : p.ry0[reg] + byi * TY, tx0 = p.stack ? 0 : p.rx0[reg] + bxi * TX;
+    const int tye = p.rye[reg], txe = p.rxe[reg];
+    const int iy0 = 2 * ty0 - p.pad, ix0 = 4 * tx0 - p.pad;
+    const int PW = 4 * TX + 2, PH = p.stack ? p.PH : 2 * TY + 2;
+    const int NPIX = PW * PH;
+    const int HS = HSC ? HSC : ((TX + 1) | 1);
+    const int PR = 8 * HS + (TX & 7);
+    const int NENT0 = PR * ((PH + 1) >> 1);
+    const int NENT = NENT0 + ((4 - NENT0) & 7);
+    const int nslots = TX * TY;
+    auto slot = [&](int id, int& g, int& ty, int& tx, int& prow) -> bool {
+        const int r = fdiv(id, TX, p.m_TX[reg]);
+        tx = tx0 + (id - r * TX);
+        if (p.stack) {
+            const int R = R0 + r;
+            const int n = fdiv(R, tys, p.m_tys);
+            g = n - n_img;
+            ty = R - n * tys;
+            prow = pitch * g + 2 * ty - prow0;
+            return id < nslots && n < p.N;
+        }
+        g = 0;
+        ty = ty0 + r;
+        prow = 2 * r;
+        return id < nslots && ty < tye && tx < txe;
+    };
+    const int vlane = PC_V + (xi * 6 * 64 + lane) * 16;        // this wave pair's row of V[0]: + buf * PC_VB + nu * 1024
+#ifdef SEAM_W24PC_TRACE
+    const bool tr_on = p.trace && blockIdx.x == SEAM_W24PC_TRACE && (wave & 3) == 0;
+    int tr_k = 0;
+#endif
+
+    f32x16 acc[6][NT];
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    if (!consumer) {
+        // ================================================= producer =================================================
+        const int ptid = tid - 256;
+#ifdef SEAM_W24PC_PRIO_P
+        __builtin_amdgcn_s_setprio(SEAM_W24PC_PRIO_P);
+#endif
+        const size_t img_bytes = (size_t)p.H * p.W * p.C * 4;
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)p.x + (size_t)n_img * img_bytes), 0, (int)(img_bytes * n_here), 0x00020000);
+        unsigned goff[NI];
+        int loff[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = ptid + 256 * i;
+            const int half = idx & 1;
+            const int pix = idx >> 1;
+            const bool ok = pix < NPIX;
+            const int v = fdiv(pix, PW, p.m_PW[reg]);
+            const int px = pix - v * PW;
+            int g = 0, gy = iy0 + v;
+            if (p.stack) {
+                const int vr = prow0 + v;
+                g = fdiv(vr, pitch, p.m_pitch);
+                gy = vr - g * pitch - p.pad;
+            }
+            const int gx = ix0 + px;
+            const bool inb = ok && g < n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            goff[i] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + half * 4) * 4) : kOob;
+            loff[i] = ok ? (half * NENT + (v >> 1) * PR + ((v & 1) * 4 + (px & 3)) * HS + (px >> 2)) * 16 : 2 * ENTMAX * 16;
+        }
+        f32x4 rset[2][NI];                      // raw patch register sets: chunk t + 2 is stored / chunk t + 4 requested in phase t
+        auto load_raw = [&](f32x4 (&rs)[NI], int chunk) {
+            const int so = chunk * 32;          // chunks past the end: next pixel's channels or zero fill, never used
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                rs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[i], so, 0));
+        };
+        auto store_raw = [&](const f32x4 (&rs)[NI], int buf) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(&raw[buf][loff[i]]) = rs[i];
+        };
+        // input transform of row xi (see w24_block): T_j = d[ra][j] + cb * d[rb][j], then B4t over the six columns
+        const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1;
+        const int rbw = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
+        const float cb = xi == 1 ? 1.f : -1.f;
+        int rbase;
+        {
+            int g, ty, tx, prow;
+            if (!slot(lane & 31, g, ty, tx, prow)) slot(0, g, ty, tx, prow);
+            rbase = ((lane >> 5) * NENT + (prow >> 1) * PR + (tx - tx0)) * 16;
+        }
+        const int oa = ((ra >> 1) * PR + (ra & 1) * 4 * HS) * 16, ob = ((rbw >> 1) * PR + (rbw & 1) * 4 * HS) * 16;
+        const int c1 = HS * 16;
+        const f32x2 cb2 = {cb, cb};
+        const f32x2 k4 = {4.f, 4.f}, km5 = {-5.f, -5.f}, km4 = {-4.f, -4.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
+        // The transform in three steps that the pipeline below places apart: the twelve patch reads (LDS: free beside the
+        // consumers' MFMAs), the 36 packed ops (vector ALU: they only run while the SIMD's matrix pipe is idle -- tools/probes/
+        // pc_probe.hip -- so they sit right in front of the barrier the consumer is about to wait at), the six fragment stores
+        // (LDS again: after the barrier, under the next chunk's MFMAs).
+        f32x4 xa[3], xb[3], ya[3], yb[3], va[6];
+        auto tr_read = [&](int buf) {
+            const char* base = &raw[buf][rbase];
+            xa[0] = *reinterpret_cast<const f32x4*>(base + oa);
+            xb[0] = *reinterpret_cast<const f32x4*>(base + ob);
+            xa[1] = *reinterpret_cast<const f32x4*>(base + oa + 2 * c1);
+            xb[1] = *reinterpret_cast<const f32x4*>(base + ob + 2 * c1);
+            xa[2] = *reinterpret_cast<const f32x4*>(base + oa + 16);
+            xb[2] = *reinterpret_cast<const f32x4*>(base + ob + 16);
+            ya[0] = *reinterpret_cast<const f32x4*>(base + oa + c1);
+            yb[0] = *reinterpret_cast<const f32x4*>(base + ob + c1);
+            ya[1] = *reinterpret_cast<const f32x4*>(base + oa + 3 * c1);
+            yb[1] = *reinterpret_cast<const f32x4*>(base + ob + 3 * c1);
+            ya[2] = *reinterpret_cast<const f32x4*>(base + oa + c1 + 16);
+            yb[2] = *reinterpret_cast<const f32x4*>(base + ob + c1 + 16);
+        };
+        auto tr_math = [&]() {
+            const f32x4 T0 = fma4s(cb2, xb[0], xa[0]), T2 = fma4s(cb2, xb[1], xa[1]), T4 = fma4s(cb2, xb[2], xa[2]);
+            const f32x4 T1 = fma4s(cb2, yb[0], ya[0]), T3 = fma4s(cb2, yb[1], ya[1]), T5 = fma4s(cb2, yb[2], ya[2]);
+            va[0] = fma4s(km5, T2, fma4s(k4, T0, T4));
+            va[5] = fma4s(km5, T3, fma4s(k4, T1, T5));
+            {
+                const f32x4 a = fma4s(km4, T2, T4), bq = fma4s(km4, T1, T3);
+                va[1] = add4(a, bq);
+                va[2] = sub4(a, bq);
+            }
+            {
+                const f32x4 c = sub4(T4, T2), d = sub4(T3, T1);
+                va[3] = fma4s(k2, d, c);
+                va[4] = fma4s(km2, d, c);
+            }
+        };
+        auto tr_write = [&](int buf) {
+            char* vrow = smem + vlane + buf * PC_VB;
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x4*>(vrow + nu * 1024) = va[nu];
+        };
+        // ---- prologue: V(0) in LDS, V(1) in registers, raw(2) in LDS, chunks 3 and 4 in flight --------------------------
+        load_raw(rset[0], 0);
+        load_raw(rset[1], 1);
+        store_raw(rset[0], 0);
+        load_raw(rset[0], 2);
+        store_raw(rset[1], 1);
+        load_raw(rset[1], 3);
+        PC_BAR();                               // P1: raw(0), raw(1) visible (the patch is shared by the four producer waves)
+        tr_read(0);
+        tr_math();
+        tr_write(0);
+        tr_read(1);
+        PC_BAR();                               // P2: every wave has read raw[0] and raw[1]
+        tr_math();                              // va = V(1)
+        asm volatile("" ::"v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(va[3]), "v"(va[4]), "v"(va[5]));
+        store_raw(rset[0], 0);                  // raw(2)
+        load_raw(rset[0], 4);
+        PC_BAR();                               // P3: V(0), raw(2) visible
+        // ---- interval t, closed by the barrier B(t + 1) inside the consumers' chunk t + 1:
+        //        V(t + 2) registers -> V[t & 1]; raw(t + 4) registers -> raw[t & 1], chunk t + 6 requested;
+        //        raw(t + 3) read from raw[(t + 1) & 1]; its 36 packed ops wait for the consumer to reach the barrier
+        auto interval = [&](int t, const int par) {
+            PC_TR(1);
+            tr_write(par);
+            if (!(SEAM_W24PC_ABL & 1)) {
+                store_raw(rset[par], par);
+                load_raw(rset[par], t + 6);
+            }
+            tr_read(par ^ 1);
+            PC_TR(2);
+            if (!(SEAM_W24PC_ABL & 8)) tr_math();
+            PC_TR(6);
+            // the fragments are inputs of the barrier statement: hipcc otherwise sinks the packed ops below it (registers only, no
+            // memory operand), i.e. into the stretch where the consumer is streaming MFMAs again
+            if (!(SEAM_W24PC_ABL & 4))
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::"v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(va[3]), "v"(va[4]), "v"(va[5]) : "memory");
+            SB();
+        };
+        for (int u = 0; u < p.nchunks; u += 2) {
+            interval(u - 1, 1);
+            interval(u, 0);
+        }
+    } else {
+        // ================================================= consumer =================================================
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nu][nt][r] = 0.f;
+#ifdef SEAM_W24PC_PRIO_C
+        __builtin_amdgcn_s_setprio(SEAM_W24PC_PRIO_C);
+#endif
+#ifdef SEAM_W24PC_AGPR       // experiment: an "a" constraint anywhere in the kernel makes hipcc select the AccVGPR form of the MFMAs
+#endif
+        const int ntile_bytes = p.nchunks * 24576;
+        const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)p.u + (size_t)tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
+        int uoff0 = (xi * 6 * 64 + lane) * 16;
+        f32x4 bq[RING][NT];                     // B fragments: slot j % RING holds position instance j = 6 * chunk + nu
+        f32x4 aq[2];                            // A fragments: position nu in aq[nu & 1]
+        auto load_b = [&](int slot_, int nu, int chunk) {
+            const int so = chunk * 24576 + (nu >> 2) * 4096;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bq[slot_][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff0 + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
+                SB();
+            }
+        };
+        auto read_a = [&](int buf, int nu) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + vlane + buf * PC_VB + nu * 1024); };
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {        // in ring order, pinned: the K loop's vmcnt waits count on it
+            SB();
+            load_b(j, j % 6, j / 6);
+        }
+        SB();
+        PC_BAR();                               // P1
+        PC_BAR();                               // P2
+        PC_BAR();                               // P3
+        aq[0] = read_a(0, 0);
+        // one chunk: positions 0..5 in order; c = chunk parity (V buffer), t = chunk index
+        auto chunk = [&](int t, const int c) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int jl = 6 * c + i, sl = jl % RING;
+                SB();
+#ifdef SEAM_W24PC_TRACE_POS
+                PC_TR(10 + i);
+#endif
+                if (i < 5) aq[(i + 1) & 1] = read_a(c, i + 1);
+                SB();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+#ifdef SEAM_W24PC_AGPR
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][nt]) : "v"(aq[i & 1][kk]), "v"(bq[sl][nt][kk]));
+#else
+                        acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i & 1][kk], bq[sl][nt][kk], acc[i][nt], 0, 0, 0);
+#endif
+                        SB();
+                    }
+                if (!(SEAM_W24PC_ABL & 2)) {
+                    const int j2 = jl + RING;                       // the instance that takes over this slot
+                    load_b(sl, j2 % 6, t - c + j2 / 6);
+                }
+                SB();
+                if (i == 4) {
+                    PC_TR(8);
+                    if (!(SEAM_W24PC_ABL & 4)) PC_BAR();
+                    PC_TR(9);
+                    aq[0] = read_a(c ^ 1, 0);
+                }
+            }
+        };
+        static_assert(12 % RING == 0, "the ring's phase repeats every two chunks");
+        for (int t = 0; t < p.nchunks; t += 2) {
+            asm volatile("" : "+v"(uoff0));
+            chunk(t, 0);
+            chunk(t + 1, 1);                    // nchunks is even (wino24_pc): one straight two-chunk body, exact vmcnt waits
+        }
+    }
+#undef SB
+
+    // ---- epilogue (v1): the consumers' 256 threads run the epilogue of conv3x3_wino24<2>; the producers keep the barriers company
+    if (SEAM_W24PC_ABL & 16) {
+        if (consumer) {
+            float sum = 0.f;
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += acc[nu][nt][r];
+            if (sum == 123456.789f) p.y[tid] = sum;
+        }
+        return;
+    }
+    const size_t out_img = (size_t)p.Ho * p.Wo * p.K * 4;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)p.y + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(p.res ? p.res : p.y) + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
+    const int et = (tid & 255) >> 3;
+    const int n4 = tid & 7;
+    int g, tyt, txt, prow_unused;
+    const bool tile_ok = slot(et, g, tyt, txt, prow_unused) && g < n_here;
+    const int oy = 2 * tyt, ox = 4 * txt;
+    const int cstep = p.K * 4, rstep = p.Wo * cstep;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ncol = (tn * NT + nt) * 32 + n4 * 4;
+        PC_BAR();                     // previous readers of `ex` (first pass: of the raw / V buffers it aliases) are done
+        if (consumer) {
+            const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                auto rd = [&](int nu) -> f32x2 { return f32x2{acc[nu][nt][2 * h], acc[nu][nt][2 * h + 1]}; };
+                const f32x2 m0 = rd(0), m1 = rd(1), m2 = rd(2), m3 = rd(3), m4 = rd(4), m5 = rd(5);
+                const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
+                const f32x2 y0 = pk_add(pk_add(m0, s12), s34);
+                const f32x2 y1 = pk_fma_s(c2, d34, d12);
+                const f32x2 y2 = pk_fma_s(c4, s34, s12);
+                const f32x2 y3 = pk_add(pk_fma_s(c8, d34, d12), m5);
+                const int r = 2 * h;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* e0 = &ex[((xi * 4 + 0) * 32 + row) * 32 + (lane & 31)];
+                e0[0] = y0[0];               e0[32] = y0[1];
+                e0[1024] = y1[0];            e0[1024 + 32] = y1[1];
+                e0[2048] = y2[0];            e0[2048 + 32] = y2[1];
+                e0[3072] = y3[0];            e0[3072 + 32] = y3[1];
+            }
+        }
+        PC_BAR();
+        // second half: the 16 (output column, row) pieces of a tile are split between the two wave groups: consumers take the
+        // output columns 0, 1, producers 2, 3 -- 512 threads store instead of 256
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + ncol);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + ncol);
+        const unsigned obase = (unsigned)(((g * p.Ho + oy) * p.Wo + ox) * p.K + ncol) * 4u;
+#pragma unroll
+        for (int bc = 0; bc < 2; ++bc) {
+            const int bcol = (consumer ? 0 : 2) + bc;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(&ex[((1 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(&ex[((2 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+            const f32x4 q3 = *reinterpret_cast<const f32x4*>(&ex[((3 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+            f32x4 yv[2];
+            yv[0] = q0 + q1 + q2;
+            yv[1] = q1 - q2 - q3;
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const bool ok = tile_ok && (oy + aa) < p.Ho && (ox + bcol) < p.Wo;
+                const unsigned off = ok ? obase + (unsigned)(aa * rstep + bcol * cstep) : kOob;
+                f32x4 v = yv[aa] * sc + sh;
+                if (p.res) {
+                    const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
+                    if (p.relu == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
+                    } else {
+                        v += rv;
+                    }
+                }
+                if (p.relu == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, off, 0, 0);
+            }
+        }
+    }
+}
+
+#ifndef SEAM_W24PC_RING
+#define SEAM_W24PC_RING 4
+#endif
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_pc[];
+    const int nblk = gridDim.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int q8 = nblk >> 3, rem8 = nblk & 7;
+    const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
+    const int tm = fdiv(tile, p.tiles_n, p.m_tiles_n);
+    const int tn = tile - tm * p.tiles_n;
+    const int per_img = p.per_img;
+    const int tm_img = fdiv(tm, per_img, p.m_per_img);
+    int rb = tm - tm_img * per_img;
+    int reg = 0;
+    if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
+        rb -= p.bx[0] * p.by[0];
+        reg = 1;
+        if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
+    }
+    const int hs = (p.TX[reg] + 1) | 1;
+    if (hs == 9) w24pc_block<9, SEAM_W24PC_RING>(p, smem_pc, reg, rb, tm, tn, tm_img);
+    else if (hs == 3) w24pc_block<3, SEAM_W24PC_RING>(p, smem_pc, reg, rb, tm, tn, tm_img);
+    else if (hs == 5) w24pc_block<5, SEAM_W24PC_RING>(p, smem_pc, reg, rb, tm, tn, tm_img);
+    else w24pc_block<0, SEAM_W24PC_RING>(p, smem_pc, reg, rb, tm, tn, tm_img);
+}
+
 // OIHW fp32 [K, Cin, 3, 3] -> U = G2 g G4t in MFMA fragment order: [K/32][Cstore/8][24][64][4]
 //   element (tn, chunk, p = 6*xi + nu, lane, e) = U_p[n = 32*tn + (lane & 31)][c = 8*chunk + 4*(lane >> 5) + e]
 // mode 0: forward weights; mode 2: input-gradient weights (taps rotated 180 degrees, channels swapped), as in
@@ -807,6 +1239,12 @@ inline int wino24_nsplit(int C, int K, long patch_blocks) {
     return 1;
 }
 
+// the producer / consumer kernel takes the NT = 2 launches (SEAM_W24_PC=0: conv3x3_wino24<2>, the round-4 kernel, stays selectable)
+inline bool wino24_pc(const Wino24Args& a) {
+    static const int want = getenv("SEAM_W24_PC") ? atoi(getenv("SEAM_W24_PC")) : 1;
+    return want && a.nt == 2 && a.nsplit == 1 && a.nchunks >= 2 && a.nchunks % 2 == 0;
+}
+
 int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long& blocks) {
     if (!wino_ok(C, K, 3, 3, 1) || N <= 0) return (int)hipErrorInvalidValue;
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K;
@@ -869,6 +1307,15 @@ long long seam_wino24_issue_slots(int N, int H, int W, int C, int K, int pad) {
     return (long long)work * a.nt * 32 * 24;
 }
 
+/* 1 when the launcher runs this layer shape on the producer / consumer kernel conv3x3_wino24pc (NT = 2 work split over two wave
+ * groups), 0 for conv3x3_wino24<NT>; -1 = unsupported shape */
+int seam_wino24_form(int N, int H, int W, int C, int K, int pad) {
+    Wino24Args a;
+    long blocks;
+    if (wino24_plan(a, N, H, W, C, K, pad, blocks)) return -1;
+    return wino24_pc(a) ? 1 : 0;
+}
+
 /* n-tiles per block (the kernel's template argument NT = 1 | 2) the launcher picks for this layer shape; 0 = unsupported */
 int seam_wino24_variant(int N, int H, int W, int C, int K, int pad) {
     Wino24Args a;
@@ -885,7 +1332,46 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
     if (rc) return rc;
     a.x = x; a.u = u_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.relu = relu;
+    a.trace = nullptr;
     static const int dyn = getenv("SEAM_W24_DYNLDS") ? atoi(getenv("SEAM_W24_DYNLDS")) : 0;     // dev knob: occupancy experiments
+    if (wino24_pc(a)) {
+        // > 64 KiB of dynamic LDS needs the attribute once per device (an atomic flag per device: the ABI is thread-safe per stream)
+        static std::atomic<unsigned> attr_done{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+            const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino24pc, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
+            if (e != hipSuccess) return (int)e;
+            attr_done.fetch_or(bit, std::memory_order_release);
+        }
+#ifdef SEAM_W24PC_TRACE
+        static unsigned long long* tbuf = nullptr;
+        if (!tbuf) hipMalloc((void**)&tbuf, 8 * 4096 * 8);
+        hipMemset(tbuf, 0, 8 * 4096 * 8);
+        a.trace = tbuf;
+#endif
+        hipLaunchKernelGGL(conv3x3_wino24pc, dim3((unsigned)blocks), dim3(512), PC_LDS, (hipStream_t)stream, a);
+#ifdef SEAM_W24PC_TRACE
+        {
+            static int dumped = 0;
+            hipDeviceSynchronize();
+            if (dumped++ == 3) {
+                static unsigned long long h[8 * 4096];
+                hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+                for (int w = 0; w < 8; w += 4) {
+                    unsigned long long prev = 0;
+                    for (int k = 0; k < 4096 && h[w * 4096 + k]; ++k) {
+                        const unsigned long long v = h[w * 4096 + k], tm = v & 0x00ffffffffffffffull;
+                        if (k >= 0) fprintf(stderr, "TR wave %d k %d tag %d t %llu d %lld\n", w, k, (int)(v >> 56), tm, prev ? (long long)(tm - prev) : 0ll);
+                        prev = tm;
+                    }
+                }
+            }
+        }
+#endif
+        return (int)hipGetLastError();
+    }
     if (a.nt == 2) hipLaunchKernelGGL(conv3x3_wino24<2>, dim3((unsigned)blocks), dim3(256), dyn, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv3x3_wino24<1>, dim3((unsigned)blocks), dim3(256), dyn, (hipStream_t)stream, a);
     return (int)hipGetLastError();

@@ -442,7 +442,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         elif sw:
             variant = _sw_variant(lib, n * h * w, c, pc.K)
         elif wino24:
-            variant = f"conv3x3_wino24<{lib.seam_wino24_variant(n, h, w, c, pc.K, pc.pad)}>"
+            variant = ("conv3x3_wino24pc" if lib.seam_wino24_form(n, h, w, c, pc.K, pc.pad) == 1
+                       else f"conv3x3_wino24<{lib.seam_wino24_variant(n, h, w, c, pc.K, pc.pad)}>")
         elif wino:
             variant = f"conv3x3_wino<{lib.seam_wino_tile_variant(n, h, w, c, pc.K, pc.pad)}>"
         elif pc.dtype == BX3:

@@ -1,0 +1,144 @@
+// pc_probe.hip -- why does a transform wave starve beside an MFMA-streaming wave of the same SIMD?  (round 5, conv3x3_wino24pc)
+// Waves 0-3 of a 512-thread block stream v_mfma_f32_32x32x2_f32 over NACC accumulator tiles (arch VGPRs, or AccVGPRs with ACCA = 1),
+// optionally with the consumer's own operand traffic (one ds_read_b128 + two buffer loads per eight MFMAs); waves 4-7 loop over
+// [NR ds_read_b128 -> wait -> NV v_pk_fma_f32 -> NW ds_write_b128 -> wait].  Prints cycles per MFMA and cycles per producer phase.
+// Build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 tools/probes/pc_probe.hip -o /tmp/pc_probe && /tmp/pc_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#pragma clang diagnostic ignored "-Wunused-value"
+#include <vector>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC, int ACCA, int OPER, int NR, int NV, int NW, int PRIO, int GAP = 0, int SWAP = 0, int PU = 1>
+__global__ __launch_bounds__(512, 2) void probe(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ stamps,
+                                               int iters) {
+    extern __shared__ char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid0 = __builtin_amdgcn_readfirstlane(tid >> 6), wid = SWAP ? (wid0 ^ 4) : wid0;   // SWAP: the MFMA waves are the YOUNGER half (hardware waves 4-7)
+    const int gw = blockIdx.x * 8 + wid;
+    *reinterpret_cast<f32x4*>(lds + tid * 16) = *reinterpret_cast<const f32x4*>(in + tid * 4);
+    *reinterpret_cast<f32x4*>(lds + 8192 + tid * 16) = *reinterpret_cast<const f32x4*>(in + tid * 4);
+    __syncthreads();
+    float s = 0.f;
+    unsigned long long t0, t1;
+    if (wid < 4) {
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int u = 0; u < NACC; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+        f32x4 a = *reinterpret_cast<const f32x4*>(in + tid * 4), b[2];
+        b[0] = a * 0.5f; b[1] = a * 0.25f;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, 1 << 20, 0x00020000);
+        if (PRIO & 1) __builtin_amdgcn_s_setprio(3);
+        t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int g = 0; g < NACC / 2; ++g) {         // one "position": 8 MFMAs on two accumulator tiles
+                f32x4 an = a, bn0 = b[0], bn1 = b[1];
+                if (OPER) {
+                    an = *reinterpret_cast<const f32x4*>(lds + lane * 16 + g * 1024);
+                    bn0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, g * 2048, 0));
+                    bn1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, g * 2048 + 1024, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (ACCA) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[2 * g + nt]) : "v"(a[kk]), "v"(b[nt][kk]));
+                        else acc[2 * g + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[nt][kk], acc[2 * g + nt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // GAP: what the MFMA wave does while its MFMA executes (the partner wave needs issue slots)
+                        if (GAP >= 1 && GAP <= 4) {
+#pragma unroll
+                            for (int q = 0; q < GAP; ++q) asm volatile("s_nop 15");
+                        }
+                        if (GAP == 5) asm volatile("s_nop 7");
+                        if (GAP == 6) asm volatile("s_nop 0");
+                        if (GAP == 7) asm volatile("s_sleep 1");
+                        if (GAP == 8) { asm volatile("s_setprio 0"); asm volatile("s_nop 15"); asm volatile("s_setprio 3"); }
+                        if (GAP == 10) asm volatile("s_branch 0");
+                        if (GAP == 11 && kk == 3 && nt == 1) asm volatile("s_branch 0");
+                        if (GAP == 12 && nt == 1) asm volatile("s_branch 0");
+                        if (GAP == 13 && kk == 3 && nt == 1) asm volatile("s_sleep 2");
+                        if (GAP == 14 && kk == 3 && nt == 1) asm volatile("s_nop 11");
+                        if (GAP == 9 && kk == 3 && nt == 1) { asm volatile("s_nop 15"); asm volatile("s_nop 15"); asm volatile("s_nop 15"); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                a = an; b[0] = bn0; b[1] = bn1;
+            }
+        }
+        t1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int u = 0; u < NACC; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[u][r];
+    } else {
+        f32x4 x[12], v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const f32x4*>(in + tid * 4) * (float)(i + 1);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) x[i] = v[i % 6];
+        const f32x2 c = {0.5f, 0.25f};
+        if (PRIO & 2) __builtin_amdgcn_s_setprio(3);
+        t0 = __builtin_readcyclecounter();
+#pragma unroll PU
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) x[i] = *reinterpret_cast<const f32x4*>(lds + 8192 + (wid - 4) * 1024 + lane * 16 + (i & 3) * 16 * 0 + (i >> 2) * 4096 * 0);
+            if (NR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f32x2& d = reinterpret_cast<f32x2*>(&v[i % 6])[(i / 6) & 1];
+                const f32x2 e = reinterpret_cast<f32x2*>(&x[i % 12])[(i / 12) & 1];
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(d) : "v"(c), "v"(e));
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) *reinterpret_cast<f32x4*>(lds + 16384 + (wid - 4) * 6144 + i * 1024 + lane * 16) = v[i];
+            if (NW) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        t1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s += v[i][0] + v[i][3];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s += x[i][1];
+    }
+    out[blockIdx.x * 512 + tid] = s;
+    if (lane == 0) stamps[gw] = t1 - t0;
+}
+
+template <int NACC, int ACCA, int OPER, int NR, int NV, int NW, int PRIO, int GAP = 0, int SWAP = 0, int PU = 1>
+void run(const float* in, float* out, unsigned long long* stamps, const char* tag) {
+    const int iters = 2000, piters = iters;
+    hipFuncSetAttribute((const void*)probe<NACC, ACCA, OPER, NR, NV, NW, PRIO, GAP, SWAP, PU>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<NACC, ACCA, OPER, NR, NV, NW, PRIO, GAP, SWAP, PU>), dim3(256), dim3(512), 65536, 0, in, out, stamps, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> st(256 * 8);
+    hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost);
+    double cm = 0, cp = 0;
+    for (int b = 0; b < 256; ++b)
+        for (int w = 0; w < 8; ++w) (w < 4 ? cm : cp) += (double)st[b * 8 + w];
+    cm /= 1024; cp /= 1024;
+    printf("gap=%d swap=%d pu=%d %-44s NACC=%2d acc=%s oper=%d | producer %2d rd %2d pk %d wr prio=%d | cyc/MFMA %6.1f | producer cyc/phase %7.1f  (MFMA waves ran %.0f, producers %.0f cycles)\n",
+           GAP, SWAP, PU, tag, NACC, ACCA ? "AGPR" : "VGPR", OPER, NR, NV, NW, PRIO, cm / (iters * NACC * 4.0), cp / piters, cm, cp);
+    fflush(stdout);
+}
+
+int main() {
+    float *in, *out; unsigned long long* stamps;
+    std::vector<float> h(1 << 18);
+    srand(1);
+    for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    hipMalloc(&in, h.size() * 4); hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMalloc(&out, 256 * 512 * 4); hipMalloc(&stamps, 256 * 8 * 8);
+    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 1>(in, out, stamps, "baseline");
+    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 2>(in, out, stamps, "producer loop unrolled x2");
+    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 4>(in, out, stamps, "producer loop unrolled x4");
+    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 8>(in, out, stamps, "producer loop unrolled x8");
+    run<12, 0, 1, 12, 0, 0, 0, 0, 0, 8>(in, out, stamps, "reads only, unrolled x8");
+    run<12, 0, 1, 0, 36, 0, 0, 0, 0, 8>(in, out, stamps, "VALU only, unrolled x8");
+    run<12, 0, 1, 0, 0, 6, 0, 0, 0, 8>(in, out, stamps, "writes only, unrolled x8");
+    return 0;
+}

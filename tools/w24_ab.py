@@ -15,8 +15,9 @@ DEFAULT = [("80,200,200,256,256,1", 2), ("2560,14,14,256,256,1", 4), ("2560,14,1
 shapes = [(a, 1) for a in sys.argv[1:] if not a.startswith("--")] or DEFAULT
 dev = torch.device("cuda:0")
 tot = 0.0
-print(f"variant: SEAM_W24_NT={os.environ.get('SEAM_W24_NT', '1')} {os.environ.get('SEAM_W24_VARIANT', '')}")
-print(f"{'N,H,W,C,K,pad':>24} {'us':>9} {'TF/s(alg)':>9} {'issued %peak':>12} {'maxdiff/scale':>13}")
+import hashlib
+print(f"variant: SEAM_W24_NT={os.environ.get('SEAM_W24_NT', 'auto')} SEAM_W24_PC={os.environ.get('SEAM_W24_PC', '1')} {os.environ.get('SEAM_W24_VARIANT', '')}")
+print(f"{'N,H,W,C,K,pad':>24} {'kernel':>18} {'us':>9} {'TF/s(alg)':>9} {'issued %peak':>12} {'maxdiff/scale':>13} {'sha(y)':>10}")
 for s, cnt in shapes:
     n, h, w, c, k, pad = map(int, s.split(","))
     g = torch.Generator(device=dev); g.manual_seed(1)
@@ -40,5 +41,8 @@ for s, cnt in shapes:
     fl = 2.0 * n * ref.shape[1] * ref.shape[2] * k * 9 * c
     diff = float((y - ref).abs().max()) / float(ref.abs().max())
     tot += us * cnt
-    print(f"{s:>24} {us:9.1f} {fl/us/1e6:9.1f} {100*fl/us/1e6/3/157.3:12.1f} {diff:13.2e}")
+    lib = _native.lib()
+    kern = "wino24pc" if lib.seam_wino24_form(n, h, w, c, k, pad) == 1 else f"wino24<{lib.seam_wino24_variant(n, h, w, c, k, pad)}>"
+    sha = hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest()[:10]
+    print(f"{s:>24} {kern:>18} {us:9.1f} {fl/us/1e6:9.1f} {100*fl/us/1e6/3/157.3:12.1f} {diff:13.2e} {sha:>10}")
 print(f"weighted total per bench step: {tot/1e3:.3f} ms")
