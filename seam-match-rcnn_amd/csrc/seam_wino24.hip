@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <atomic>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -155,6 +156,7 @@ struct Wino24Args {
     // patches (tm) cut into 8 / nsplit partitions of part_q (+1 for the first part_r) each
     int nsplit, tns, part_q, part_r;
     unsigned m_tns;
+    int total_tiles;             // conv3x3_wino24pc: tiles of the launch (the grid is persistent: min(tiles, CUs) blocks)
     unsigned long long* trace;   // SEAM_W24PC_TRACE builds only: s_memtime stamps of one block's waves 0 and 4 (else null)
 };
 
@@ -641,169 +643,319 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
 }
 
 // =====================================================================================================================
-// conv3x3_wino24pc (round 5): the NT = 2 block as a PRODUCER / CONSUMER pair of wave groups -- two waves per SIMD.
+// conv3x3_wino24pc (round 5): the NT = 2 block as a PRODUCER / CONSUMER pair of wave groups, two waves per SIMD, persistent.
 //
-// What round 4 measured on conv3x3_wino24<2>: the block is alone on its CU (one wave per SIMD, 490 registers), and within ONE
-// wave nothing vector-ALU overlaps an fp32 MFMA -- the input transform (36 packed ops), the patch loads / LDS stores and the
-// waits behind them cost ~17 % of every chunk -- while ANOTHER wave of the same SIMD runs VALU / LDS / memory instructions
-// beside an MFMA-streaming wave for free (tools/mfma_shadow_probe.hip).  So the work is split by role:
+// What round 4 measured on conv3x3_wino24<2>: the block is alone on its CU (one wave per SIMD, 490 registers), so everything that
+// is not an MFMA is exposed -- the input transform, the patch loads / LDS stores, the waits behind them: ~17 % of every chunk plus a
+// fixed 5.3 us per block.  What tools/probes/pc_probe.hip measured this round: beside a wave that streams fp32 MFMAs back to back,
+// its SIMD partner's LDS, vector-memory and scalar instructions are free, but its VECTOR-ALU instructions do not issue at all until
+// the matrix pipe idles (fp32 MFMA and fp32 VALU share the SIMD's FMA lanes).  So the work is split by role, and the one thing
+// that has to share the pipe -- the 36 packed ops of a chunk's input transform -- is placed where the consumer yields anyway:
 //   waves 0..3 (consumers, one per SIMD): MFMAs only.  Wave xi owns the positions (xi, nu = 0..5) x 32 tiles x 64 channels
 //     (192 accumulators, all arch VGPRs: with 512 threads per block the budget is 256 registers and hipcc selects the VGPR
-//     form of the MFMA, no AccVGPRs).  Its A fragments come from LDS (`ds_read_b128`, one position ahead), its B fragments
-//     straight from global memory through a small register ring (RING positions x 8 registers, refilled right behind the
-//     MFMAs that read them); its K loop holds no vector-ALU instruction at all.
-//   waves 4..7 (producers, the SIMD partners of 0..3): load the raw patch two chunks ahead (registers -> LDS), compute the
-//     input transform of chunk t + 1 while the consumers multiply chunk t, and write the A fragments to LDS in MFMA layout
-//     V[buf][xi][nu][lane][16 B] (the lane that computes a fragment element is the lane that consumes it: conflict-free
-//     1-KiB rows both ways).
-//   One s_barrier per chunk, placed in the consumer between positions 4 and 5: by then it holds the last fragment of chunk t
-//     in registers, so the producers may overwrite V[t & 1] with chunk t + 2 while the consumer requests chunk t + 1's first
-//     fragment under the eight MFMAs of position 5 -- the LDS latency never faces the matrix pipe.
+//     form of the MFMA).  A fragments come from LDS (`ds_read_b128`, one position ahead), B fragments straight from global
+//     memory through a register ring (RING positions x 8 registers, refilled right behind the MFMAs that read them); the K loop
+//     holds no vector-ALU instruction; the first k-step of a tile multiplies into a zero constant (no accumulator clears).
+//   waves 4..7 (producers, the SIMD partners): a software pipeline over the block's chunk stream, one interval per consumer
+//     chunk -- fragments of chunk t + 2 registers -> LDS V[t & 1]; raw patch of chunk t + 4 registers -> LDS raw[t & 1]; global
+//     loads of chunk t + 6; LDS reads of chunk t + 3's raw patch (all free beside the MFMAs); then the 36 packed ops of chunk
+//     t + 3, which run while the consumer waits at the chunk's barrier; then the barrier.  The pipeline runs ACROSS tiles: a block
+//     is persistent (grid = CUs, XCD-contiguous tile ranges), the next tile's address set-up is computed nine intervals before
+//     the current tile ends and the load / store / read stages switch over one by one, so a tile's prologue (first patch
+//     latency, two transforms) disappears behind the previous tile's last chunks and epilogue.
+//   One s_barrier per chunk, in the consumer between positions 4 and 5: it then holds the chunk's last fragment in registers
+//     and requests the next chunk's first one under the eight MFMAs of position 5.
+//   Epilogue: consumers run the nu half of the output transform into the exchange array (its own 64 KiB: the raw / V buffers hold
+//     the next tile's data by then), all 512 threads finish (xi half, scale / shift / residual / ReLU, 16-byte stores).
 // The arithmetic (transform expressions, accumulation order, epilogue) is that of conv3x3_wino24<2>: results are bit-identical.
 // =====================================================================================================================
 #ifndef SEAM_W24PC_ABL
-#define SEAM_W24PC_ABL 0    // experiments: 1 no in-loop patch loads / stores, 2 no in-loop weight loads, 4 no in-loop barrier, 8 no in-loop transforms, 16 no epilogue
+#define SEAM_W24PC_ABL 0    // experiments: 1 no in-loop patch loads / stores, 2 no in-loop weight loads, 8 no in-loop transforms, 16 no epilogue arithmetic
+#endif
+#ifndef SEAM_W24PC_RING
+#define SEAM_W24PC_RING 4
 #endif
 constexpr int PC_VB = 4 * 6 * 64 * 16;                 // bytes per V buffer
-constexpr int PC_RAW = 0, PC_V = 2 * RAWB;             // LDS map: raw[2] | V[2]   (the epilogue's exchange array aliases all of it)
+constexpr int PC_RAW = 0, PC_V = 2 * RAWB, PC_EX = 2 * RAWB + 2 * PC_VB;      // LDS map: raw[2] | V[2] | ex
 constexpr int PC_EXB = 4 * 4 * 32 * 32 * 4;
-constexpr int PC_LDS = (2 * RAWB + 2 * PC_VB) > PC_EXB ? (2 * RAWB + 2 * PC_VB) : PC_EXB;
-static_assert((2 * RAWB) % 16 == 0, "V buffers are 16-byte aligned");
+constexpr int PC_LDS = PC_EX + PC_EXB;
+static_assert((2 * RAWB) % 16 == 0 && PC_LDS <= 160 * 1024, "LDS map");
 
 #define PC_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define LDSQ __attribute__((address_space(3)))
 #ifdef SEAM_W24PC_TRACE      // debug: stamp (tag << 56 | s_memtime) into p.trace[wave * 4096 + k++] from lane 0 of the traced block
 #define PC_TR(tag) do { if (tr_on) { const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && tr_k < 4096) p.trace[wave * 4096 + tr_k] = tm_ | ((unsigned long long)(tag) << 56); ++tr_k; } } while (0)
 #else
 #define PC_TR(tag) do { } while (0)
 #endif
 
-template <int HSC, int RING>
-__device__ __forceinline__ void w24pc_block(const Wino24Args& p, char* smem, const int reg, const int rb, const int tm, const int tn,
-                                            const int tm_img) {
+// wave-uniform geometry of one tile (SGPRs; recomputed from the tile index where it is needed rather than kept alive)
+struct PcGeo {
+    int tn, reg, n_img, n_here, R0, prow0, ty0, tx0, iy0, ix0, TX, PW, NPIX, HS, PR, NENT, nslots;
+};
+__device__ __forceinline__ PcGeo pc_geo(const Wino24Args& p, const int tile) {
+    PcGeo g;
+    const int tm = fdiv(tile, p.tiles_n, p.m_tiles_n);
+    g.tn = tile - tm * p.tiles_n;
+    const int tm_img = fdiv(tm, p.per_img, p.m_per_img);
+    int rb = tm - tm_img * p.per_img;
+    int reg = 0;
+    if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
+        rb -= p.bx[0] * p.by[0];
+        reg = 1;
+        if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
+    }
+    g.reg = reg;
+    const int TX = p.TX[reg], TY = p.TY[reg];
+    const int byi = fdiv(rb, p.bx[reg], p.m_bx[reg]);
+    const int bxi = rb - byi * p.bx[reg];
+    g.R0 = tm * TY;
+    g.n_img = p.stack ? fdiv(g.R0, p.tiles_y, p.m_tys) : tm_img;
+    g.prow0 = p.stack ? 2 * (g.R0 - g.n_img * p.tiles_y) : 0;
+    g.n_here = min(p.G, p.N - g.n_img);
+    g.ty0 = p.stack ? 0 : p.ry0[reg] + byi * TY;
+    g.tx0 = p.stack ? 0 : p.rx0[reg] + bxi * TX;
+    g.iy0 = 2 * g.ty0 - p.pad;
+    g.ix0 = 4 * g.tx0 - p.pad;
+    g.TX = TX;
+    g.PW = 4 * TX + 2;
+    const int PH = p.stack ? p.PH : 2 * TY + 2;
+    g.NPIX = g.PW * PH;
+    g.HS = (TX + 1) | 1;
+    g.PR = 8 * g.HS + (TX & 7);
+    const int NENT0 = g.PR * ((PH + 1) >> 1);
+    g.NENT = NENT0 + ((4 - NENT0) & 7);
+    g.nslots = TX * TY;
+    return g;
+}
+// tile slot id (0..31) of a block patch -> image-in-group g, tile row / column, first patch row; false for idle slots
+__device__ __forceinline__ bool pc_slot(const Wino24Args& p, const PcGeo& q, int id, int& g, int& ty, int& tx, int& prow) {
+    const int r = fdiv(id, q.TX, p.m_TX[q.reg]);
+    tx = q.tx0 + (id - r * q.TX);
+    if (p.stack) {
+        const int R = q.R0 + r;
+        const int n = fdiv(R, p.tiles_y, p.m_tys);
+        g = n - q.n_img;
+        ty = R - n * p.tiles_y;
+        prow = (2 * p.tiles_y + 2) * g + 2 * ty - q.prow0;
+        return id < q.nslots && n < p.N;
+    }
+    g = 0;
+    ty = q.ty0 + r;
+    prow = 2 * r;
+    return id < q.nslots && ty < p.rye[q.reg] && tx < p.rxe[q.reg];
+}
+
+// second half of the epilogue for one n-tile (all 512 threads; consumers take the output columns 0, 1 of a tile, producers 2, 3).
+// sc / sh: this thread's four channels of the epilogue vectors, requested by the caller ahead of the barrier in front of this call.
+struct PcEpi { f32x4 sc[2], sh[2]; };
+__device__ __forceinline__ void pc_epi_vectors(const Wino24Args& p, const PcGeo& q, const int tid, PcEpi& e) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int ncol = (q.tn * 2 + nt) * 32 + (tid & 7) * 4;
+        e.sc[nt] = f32x4{1.f, 1.f, 1.f, 1.f};
+        e.sh[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.scale) e.sc[nt] = *reinterpret_cast<const f32x4*>(p.scale + ncol);
+        if (p.shift) e.sh[nt] = *reinterpret_cast<const f32x4*>(p.shift + ncol);
+    }
+}
+__device__ __forceinline__ void pc_finish(const Wino24Args& p, const PcGeo& q, const float* ex, const int nt, const int tid, const bool consumer,
+                                          const PcEpi& epi) {
+    const int et = (tid & 255) >> 3;
+    const int n4 = tid & 7;
+    int g, tyt, txt, prow_unused;
+    const bool tile_ok = pc_slot(p, q, et, g, tyt, txt, prow_unused) && g < q.n_here;
+    const int oy = 2 * tyt, ox = 4 * txt;
+    const int cstep = p.K * 4, rstep = p.Wo * cstep;
+    const size_t out_img = (size_t)p.Ho * p.Wo * p.K * 4;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)p.y + (size_t)q.n_img * out_img), 0, (int)(out_img * q.n_here), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(p.res ? p.res : p.y) + (size_t)q.n_img * out_img), 0, (int)(out_img * q.n_here), 0x00020000);
+    const int ncol = (q.tn * 2 + nt) * 32 + n4 * 4;
+    const f32x4 sc = epi.sc[nt], sh = epi.sh[nt];
+    const unsigned obase = (unsigned)(((g * p.Ho + oy) * p.Wo + ox) * p.K + ncol) * 4u;
+    unsigned off[2][2];
+    f32x4 rv[2][2];
+#pragma unroll
+    for (int bc = 0; bc < 2; ++bc)
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa) {
+            const int bcol = (consumer ? 0 : 2) + bc;
+            const bool ok = tile_ok && (oy + aa) < p.Ho && (ox + bcol) < p.Wo;
+            off[bc][aa] = ok ? obase + (unsigned)(aa * rstep + bcol * cstep) : kOob;
+            if (p.res) rv[bc][aa] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off[bc][aa], 0, 0));   // all four ahead of the LDS reads
+        }
+#pragma unroll
+    for (int bc = 0; bc < 2; ++bc) {
+        const int bcol = (consumer ? 0 : 2) + bc;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(&ex[((1 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(&ex[((2 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+        const f32x4 q3 = *reinterpret_cast<const f32x4*>(&ex[((3 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+        f32x4 yv[2];
+        yv[0] = q0 + q1 + q2;
+        yv[1] = q1 - q2 - q3;
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa) {
+            f32x4 v = yv[aa] * sc + sh;
+            if (p.res) {
+                if (p.relu == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = rv[bc][aa][e] > 0.f ? v[e] : 0.f;
+                } else {
+                    v += rv[bc][aa];
+                }
+            }
+            if (p.relu == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, off[bc][aa], 0, 0);
+        }
+    }
+}
+
+template <int RING>
+__global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
     constexpr int NT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char (*raw)[RAWB] = reinterpret_cast<char (*)[RAWB]>(smem + PC_RAW);
-    float* const ex = reinterpret_cast<float*>(smem);
+    float* const ex = reinterpret_cast<float*>(smem + PC_EX);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < 4;
     const int xi = wave & 3;
-    const int TX = p.TX[reg], TY = p.TY[reg];
-    const int byi = fdiv(rb, p.bx[reg], p.m_bx[reg]);
-    const int bxi = rb - byi * p.bx[reg];
-    const int tys = p.tiles_y, pitch = 2 * tys + 2;
-    const int R0 = tm * TY;
-    const int n_img = p.stack ? fdiv(R0, tys, p.m_tys) : tm_img;
-    const int prow0 = p.stack ? 2 * (R0 - n_img * tys) : 0;
-    const int n_here = min(p.G, p.N - n_img);
-    const int ty0 = p.stack ? 0 : p.ry0[reg] + byi * TY, tx0 = p.stack ? 0 : p.rx0[reg] + bxi * TX;
-    const int tye = p.rye[reg], txe = p.rxe[reg];
-    const int iy0 = 2 * ty0 - p.pad, ix0 = 4 * tx0 - p.pad;
-    const int PW = 4 * TX + 2, PH = p.stack ? p.PH : 2 * TY + 2;
-    const int NPIX = PW * PH;
-    const int HS = HSC ? HSC : ((TX + 1) | 1);
-    const int PR = 8 * HS + (TX & 7);
-    const int NENT0 = PR * ((PH + 1) >> 1);
-    const int NENT = NENT0 + ((4 - NENT0) & 7);
-    const int nslots = TX * TY;
-    auto slot = [&](int id, int& g, int& ty, int& tx, int& prow) -> bool {
-        const int r = fdiv(id, TX, p.m_TX[reg]);
-        tx = tx0 + (id - r * TX);
-        if (p.stack) {
-            const int R = R0 + r;
-            const int n = fdiv(R, tys, p.m_tys);
-            g = n - n_img;
-            ty = R - n * tys;
-            prow = pitch * g + 2 * ty - prow0;
-            return id < nslots && n < p.N;
-        }
-        g = 0;
-        ty = ty0 + r;
-        prow = 2 * r;
-        return id < nslots && ty < tye && tx < txe;
-    };
+    const int n = p.nchunks;
+
+    // ---- the block's tiles: XCD x (= blockIdx & 7) owns a contiguous range of the launch's tiles; its blocks walk it interleaved ----
+    const int T = p.total_tiles;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, sl0 = blockIdx.x >> 3;
+    const int q8 = T >> 3, rem8 = T & 7;
+    const int cnt = q8 + (xcd < rem8 ? 1 : 0);
+    const int start = xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8;
+    const int S = (G >> 3) + ((G & 7) > xcd ? 1 : 0);
+    const int ntiles = sl0 < cnt ? (cnt - sl0 + S - 1) / S : 0;
+    if (ntiles == 0) return;
+    const int tile0 = start + sl0;
+
     const int vlane = PC_V + (xi * 6 * 64 + lane) * 16;        // this wave pair's row of V[0]: + buf * PC_VB + nu * 1024
 #ifdef SEAM_W24PC_TRACE
     const bool tr_on = p.trace && blockIdx.x == SEAM_W24PC_TRACE && (wave & 3) == 0;
     int tr_k = 0;
 #endif
-
-    f32x16 acc[6][NT];
 #define SB() __builtin_amdgcn_sched_barrier(0)
+
     if (!consumer) {
-        // ================================================= producer =================================================
+        // =================================================== producer ===================================================
         const int ptid = tid - 256;
-#ifdef SEAM_W24PC_PRIO_P
-        __builtin_amdgcn_s_setprio(SEAM_W24PC_PRIO_P);
-#endif
         const size_t img_bytes = (size_t)p.H * p.W * p.C * 4;
-        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((const char*)p.x + (size_t)n_img * img_bytes), 0, (int)(img_bytes * n_here), 0x00020000);
-        unsigned goff[NI];
-        int loff[NI];
+        constexpr int NP = 12;                  // 16-byte patch pieces per thread and GROUP of four chunks (one 128-byte line per pixel)
+        // Address state of the three stages that touch a tile's geometry.  Each piece is recomputed for the next tile (vector ALU,
+        // in a burst window) right after its stage has used it for the last time, so one set serves the whole pipeline.
+        //   A patch pixel's 32 channels of a group are ONE 128-byte line: eight adjacent lanes fetch it with one 16-byte piece each
+        //   (round 5: the per-chunk form -- two lanes per line, four visits per line -- missed the 32 KiB L1 every time: 4 x the
+        //   L2 requests, and the vector-memory queue it kept busy held back the consumers' weight loads).
+        unsigned goff[NP];                      // load stage: global byte offset of piece (ptid & 7) of pixel (ptid >> 3) + 32 r; kOob outside
+        LDSQ char* lp[NP];                      // store stage: LDS address of that piece inside raw[0] (its chunk = piece >> 1, half = piece & 1)
+        LDSQ char* ra[4];                       // read stage: LDS addresses (raw[0]) of the transform's two patch rows at x phases 0..3
+        LDSQ char* rb[4];
+        LDSQ char* lpn[NP];                     // the next tile's lp, computed together with its goff (same pixel arithmetic)
+        auto setup_patch = [&](const PcGeo& q, LDSQ char* (&lp_)[NP]) {
+            const int pitch = 2 * p.tiles_y + 2;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int idx = ptid + 256 * i;
-            const int half = idx & 1;
-            const int pix = idx >> 1;
-            const bool ok = pix < NPIX;
-            const int v = fdiv(pix, PW, p.m_PW[reg]);
-            const int px = pix - v * PW;
-            int g = 0, gy = iy0 + v;
-            if (p.stack) {
-                const int vr = prow0 + v;
-                g = fdiv(vr, pitch, p.m_pitch);
-                gy = vr - g * pitch - p.pad;
+            for (int r = 0; r < NP; ++r) {
+                const int pix = (ptid >> 3) + 32 * r;
+                const int v = fdiv(pix, q.PW, p.m_PW[q.reg]);
+                const int px = pix - v * q.PW;
+                int g = 0, gy = q.iy0 + v;
+                if (p.stack) {
+                    const int vr = q.prow0 + v;
+                    g = fdiv(vr, pitch, p.m_pitch);
+                    gy = vr - g * pitch - p.pad;
+                }
+                const int gx = q.ix0 + px;
+                const bool inb = pix < q.NPIX && g < q.n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                goff[r] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + (ptid & 7) * 4) * 4) : kOob;
+                const int half = ptid & 1;
+                lp_[r] = (LDSQ char*)smem + PC_RAW +
+                         (pix < q.NPIX ? (half * q.NENT + (v >> 1) * q.PR + ((v & 1) * 4 + (px & 3)) * q.HS + (px >> 2)) * 16 : 2 * ENTMAX * 16);
             }
-            const int gx = ix0 + px;
-            const bool inb = ok && g < n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            goff[i] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + half * 4) * 4) : kOob;
-            loff[i] = ok ? (half * NENT + (v >> 1) * PR + ((v & 1) * 4 + (px & 3)) * HS + (px >> 2)) * 16 : 2 * ENTMAX * 16;
-        }
-        f32x4 rset[2][NI];                      // raw patch register sets: chunk t + 2 is stored / chunk t + 4 requested in phase t
-        auto load_raw = [&](f32x4 (&rs)[NI], int chunk) {
-            const int so = chunk * 32;          // chunks past the end: next pixel's channels or zero fill, never used
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                rs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[i], so, 0));
         };
-        auto store_raw = [&](const f32x4 (&rs)[NI], int buf) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(&raw[buf][loff[i]]) = rs[i];
-        };
-        // input transform of row xi (see w24_block): T_j = d[ra][j] + cb * d[rb][j], then B4t over the six columns
-        const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1;
-        const int rbw = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
-        const float cb = xi == 1 ? 1.f : -1.f;
-        int rbase;
-        {
+        auto setup_read = [&](const PcGeo& q) {
+            // input transform of row xi: T_j = d[ra][j] + cb * d[rb][j]  (rows: xi0: d0 - d2, xi1: d1 + d2, xi2: d2 - d1, xi3: d1 - d3)
+            const int rwa = xi == 0 ? 0 : xi == 2 ? 2 : 1;
+            const int rwb = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
             int g, ty, tx, prow;
-            if (!slot(lane & 31, g, ty, tx, prow)) slot(0, g, ty, tx, prow);
-            rbase = ((lane >> 5) * NENT + (prow >> 1) * PR + (tx - tx0)) * 16;
-        }
-        const int oa = ((ra >> 1) * PR + (ra & 1) * 4 * HS) * 16, ob = ((rbw >> 1) * PR + (rbw & 1) * 4 * HS) * 16;
-        const int c1 = HS * 16;
+            if (!pc_slot(p, q, lane & 31, g, ty, tx, prow)) pc_slot(p, q, 0, g, ty, tx, prow);     // idle slots read tile 0 (never stored)
+            const int rbase = ((lane >> 5) * q.NENT + (prow >> 1) * q.PR + (tx - q.tx0)) * 16;
+            const int oa = ((rwa >> 1) * q.PR + (rwa & 1) * 4 * q.HS) * 16, ob = ((rwb >> 1) * q.PR + (rwb & 1) * 4 * q.HS) * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {       // column j: x phase (j & 3) at entry (j >> 2)
+                ra[j] = (LDSQ char*)smem + PC_RAW + rbase + oa + j * q.HS * 16;
+                rb[j] = (LDSQ char*)smem + PC_RAW + rbase + ob + j * q.HS * 16;
+            }
+        };
+        auto x_desc = [&](const PcGeo& q) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (size_t)q.n_img * img_bytes), 0, (int)(img_bytes * q.n_here), 0x00020000);
+        };
+        const float cb = xi == 1 ? 1.f : -1.f;
         const f32x2 cb2 = {cb, cb};
         const f32x2 k4 = {4.f, 4.f}, km5 = {-5.f, -5.f}, km4 = {-4.f, -4.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
-        // The transform in three steps that the pipeline below places apart: the twelve patch reads (LDS: free beside the
-        // consumers' MFMAs), the 36 packed ops (vector ALU: they only run while the SIMD's matrix pipe is idle -- tools/probes/
-        // pc_probe.hip -- so they sit right in front of the barrier the consumer is about to wait at), the six fragment stores
-        // (LDS again: after the barrier, under the next chunk's MFMAs).
+
+        __amdgpu_buffer_rsrc_t rsrcL;
+        int gL = 0;                             // next group (of its tile) the load stage requests
+        {
+            const PcGeo q0 = pc_geo(p, tile0);
+            setup_patch(q0, lp);
+            setup_read(q0);
+            rsrcL = x_desc(q0);
+        }
+        f32x4 rq[2][NP];                        // the pieces of two groups (group parity)
         f32x4 xa[3], xb[3], ya[3], yb[3], va[6];
+        auto load_group = [&](f32x4 (&dst)[NP]) {      // request group gL of the load stage's tile
+            const int so = gL * 128;            // groups past the end: the next pixel's channels or zero fill, never used
+#pragma unroll
+            for (int r = 0; r < NP; ++r)
+                dst[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcL, goff[r], so, 0));
+            ++gL;
+        };
+        // chunk (cq = 0..3 of its group) -> LDS raw[buf]: the sixteen lanes per instruction that hold this chunk's pieces store them
+        // (exec mask by immediate; scalar + LDS instructions only -- a v_cmp in front of the stores would not issue before the consumer yields)
+#define PC_ST1(i) "ds_write_b128 %" #i ", %[d" #i "] offset:%[off]\n\t"
+#define PC_STORE12(MASK, src, buf)                                                                                                          \
+        asm volatile("s_mov_b32 exec_lo, " MASK "\n\ts_mov_b32 exec_hi, " MASK "\n\t"                                                        \
+                     PC_ST1(0) PC_ST1(1) PC_ST1(2) PC_ST1(3) PC_ST1(4) PC_ST1(5) PC_ST1(6) PC_ST1(7) PC_ST1(8) PC_ST1(9) PC_ST1(10) PC_ST1(11)  \
+                     "s_mov_b64 exec, -1"                                                                                                    \
+                     :: "v"(lp[0]), "v"(lp[1]), "v"(lp[2]), "v"(lp[3]), "v"(lp[4]), "v"(lp[5]), "v"(lp[6]), "v"(lp[7]), "v"(lp[8]), "v"(lp[9]),  \
+                        "v"(lp[10]), "v"(lp[11]), [d0] "v"(src[0]), [d1] "v"(src[1]), [d2] "v"(src[2]), [d3] "v"(src[3]), [d4] "v"(src[4]),    \
+                        [d5] "v"(src[5]), [d6] "v"(src[6]), [d7] "v"(src[7]), [d8] "v"(src[8]), [d9] "v"(src[9]), [d10] "v"(src[10]),          \
+                        [d11] "v"(src[11]), [off] "n"((buf) * RAWB) : "memory")
+        auto store_chunk = [&](const f32x4 (&src)[NP], const int cq, const int buf) {
+            if (cq == 0) { if (buf) PC_STORE12("0x03030303", src, 1); else PC_STORE12("0x03030303", src, 0); }
+            if (cq == 1) { if (buf) PC_STORE12("0x0c0c0c0c", src, 1); else PC_STORE12("0x0c0c0c0c", src, 0); }
+            if (cq == 2) { if (buf) PC_STORE12("0x30303030", src, 1); else PC_STORE12("0x30303030", src, 0); }
+            if (cq == 3) { if (buf) PC_STORE12("0xc0c0c0c0", src, 1); else PC_STORE12("0xc0c0c0c0", src, 0); }
+        };
+        // The transform in three steps that the pipeline places apart: twelve patch reads (LDS), 36 packed ops (vector ALU: they
+        // only run while the matrix pipe is idle, so they sit in front of the barrier the consumer is about to wait at), six
+        // fragment stores (LDS again: behind the barrier, under the next chunk's MFMAs).
         auto tr_read = [&](int buf) {
-            const char* base = &raw[buf][rbase];
-            xa[0] = *reinterpret_cast<const f32x4*>(base + oa);
-            xb[0] = *reinterpret_cast<const f32x4*>(base + ob);
-            xa[1] = *reinterpret_cast<const f32x4*>(base + oa + 2 * c1);
-            xb[1] = *reinterpret_cast<const f32x4*>(base + ob + 2 * c1);
-            xa[2] = *reinterpret_cast<const f32x4*>(base + oa + 16);
-            xb[2] = *reinterpret_cast<const f32x4*>(base + ob + 16);
-            ya[0] = *reinterpret_cast<const f32x4*>(base + oa + c1);
-            yb[0] = *reinterpret_cast<const f32x4*>(base + ob + c1);
-            ya[1] = *reinterpret_cast<const f32x4*>(base + oa + 3 * c1);
-            yb[1] = *reinterpret_cast<const f32x4*>(base + ob + 3 * c1);
-            ya[2] = *reinterpret_cast<const f32x4*>(base + oa + c1 + 16);
-            yb[2] = *reinterpret_cast<const f32x4*>(base + ob + c1 + 16);
+            const int bo = buf * RAWB;
+            xa[0] = *reinterpret_cast<const f32x4 LDSQ*>(ra[0] + bo);
+            xb[0] = *reinterpret_cast<const f32x4 LDSQ*>(rb[0] + bo);
+            xa[1] = *reinterpret_cast<const f32x4 LDSQ*>(ra[2] + bo);
+            xb[1] = *reinterpret_cast<const f32x4 LDSQ*>(rb[2] + bo);
+            xa[2] = *reinterpret_cast<const f32x4 LDSQ*>(ra[0] + bo + 16);
+            xb[2] = *reinterpret_cast<const f32x4 LDSQ*>(rb[0] + bo + 16);
+            ya[0] = *reinterpret_cast<const f32x4 LDSQ*>(ra[1] + bo);
+            yb[0] = *reinterpret_cast<const f32x4 LDSQ*>(rb[1] + bo);
+            ya[1] = *reinterpret_cast<const f32x4 LDSQ*>(ra[3] + bo);
+            yb[1] = *reinterpret_cast<const f32x4 LDSQ*>(rb[3] + bo);
+            ya[2] = *reinterpret_cast<const f32x4 LDSQ*>(ra[1] + bo + 16);
+            yb[2] = *reinterpret_cast<const f32x4 LDSQ*>(rb[1] + bo + 16);
         };
         auto tr_math = [&]() {
             const f32x4 T0 = fma4s(cb2, xb[0], xa[0]), T2 = fma4s(cb2, xb[1], xa[1]), T4 = fma4s(cb2, xb[2], xa[2]);
@@ -821,18 +973,17 @@ __device__ __forceinline__ void w24pc_block(const Wino24Args& p, char* smem, con
                 va[4] = fma4s(km2, d, c);
             }
         };
+        LDSQ char* const vrow0 = (LDSQ char*)smem + vlane;
         auto tr_write = [&](int buf) {
-            char* vrow = smem + vlane + buf * PC_VB;
 #pragma unroll
-            for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x4*>(vrow + nu * 1024) = va[nu];
+            for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x4 LDSQ*>(vrow0 + buf * PC_VB + nu * 1024) = va[nu];
         };
-        // ---- prologue: V(0) in LDS, V(1) in registers, raw(2) in LDS, chunks 3 and 4 in flight --------------------------
-        load_raw(rset[0], 0);
-        load_raw(rset[1], 1);
-        store_raw(rset[0], 0);
-        load_raw(rset[0], 2);
-        store_raw(rset[1], 1);
-        load_raw(rset[1], 3);
+#define PC_PIN_VA() asm volatile("" ::"v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(va[3]), "v"(va[4]), "v"(va[5]))
+        // ---- prologue of the block's first tile: V(0) in LDS, V(1) in registers, raw(2) in LDS, chunk 3 in registers, group 1 in flight
+        load_group(rq[0]);
+        load_group(rq[1]);
+        store_chunk(rq[0], 0, 0);
+        store_chunk(rq[0], 1, 1);
         PC_BAR();                               // P1: raw(0), raw(1) visible (the patch is shared by the four producer waves)
         tr_read(0);
         tr_math();
@@ -840,233 +991,213 @@ __device__ __forceinline__ void w24pc_block(const Wino24Args& p, char* smem, con
         tr_read(1);
         PC_BAR();                               // P2: every wave has read raw[0] and raw[1]
         tr_math();                              // va = V(1)
-        asm volatile("" ::"v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(va[3]), "v"(va[4]), "v"(va[5]));
-        store_raw(rset[0], 0);                  // raw(2)
-        load_raw(rset[0], 4);
+        PC_PIN_VA();
+        store_chunk(rq[0], 2, 0);               // raw(2)
         PC_BAR();                               // P3: V(0), raw(2) visible
-        // ---- interval t, closed by the barrier B(t + 1) inside the consumers' chunk t + 1:
-        //        V(t + 2) registers -> V[t & 1]; raw(t + 4) registers -> raw[t & 1], chunk t + 6 requested;
-        //        raw(t + 3) read from raw[(t + 1) & 1]; its 36 packed ops wait for the consumer to reach the barrier
-        auto interval = [&](int t, const int par) {
-            PC_TR(1);
-            tr_write(par);
-            if (!(SEAM_W24PC_ABL & 1)) {
-                store_raw(rset[par], par);
-                load_raw(rset[par], t + 6);
-            }
-            tr_read(par ^ 1);
-            PC_TR(2);
-            if (!(SEAM_W24PC_ABL & 8)) tr_math();
-            PC_TR(6);
-            // the fragments are inputs of the barrier statement: hipcc otherwise sinks the packed ops below it (registers only, no
-            // memory operand), i.e. into the stretch where the consumer is streaming MFMAs again
-            if (!(SEAM_W24PC_ABL & 4))
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::"v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(va[3]), "v"(va[4]), "v"(va[5]) : "memory");
-            SB();
+
+        // ---- interval i of a tile (i = 0 .. n - 1), closed by the barrier inside the consumers' chunk i:
+        //        fragments of chunk i + 1: registers -> V[(i + 1) & 1];   patch of chunk i + 3: registers -> raw[(i + 3) & 1];
+        //        every fourth interval (chunk i + 3 was its group's last): request group (i + 3) / 4 + 2 into the freed registers;
+        //        patch of chunk i + 2: raw[i & 1] -> registers, then its 36 packed ops; barrier.
+        //      Chunks >= n of a tile ARE the next tile's first chunks: the request stage moves to the next tile after interval
+        //      n - 12 (its addresses are recomputed in the burst window of interval n - 9), the store stage after n - 4, the read
+        //      stage after n - 3 -- each piece of address state right behind its last use, so nothing is selected at run time.
+        //      The tile's epilogue (second halves) follows its last interval; the next tile's interval 0 starts behind it.
+        auto finish_prev = [&](const int tile_prev) {   // a finished tile's epilogue, second halves (barriers E1, E2, E3)
+            const PcGeo qp = pc_geo(p, tile_prev);
+            PcEpi epi;
+            pc_epi_vectors(p, qp, tid, epi);    // requested here, used behind the barrier
+            PC_TR(30);
+            PC_BAR();                           // E1: ex holds n-tile 0
+            PC_TR(31);
+            if (!(SEAM_W24PC_ABL & 16)) pc_finish(p, qp, ex, 0, tid, false, epi);
+            PC_TR(32);
+            PC_BAR();                           // E2: ex is free again
+            PC_TR(33);
+            PC_BAR();                           // E3: ex holds n-tile 1
+            PC_TR(34);
+            if (!(SEAM_W24PC_ABL & 16)) pc_finish(p, qp, ex, 1, tid, false, epi);
+            PC_TR(35);
         };
-        for (int u = 0; u < p.nchunks; u += 2) {
-            interval(u - 1, 1);
-            interval(u, 0);
+        int tile = tile0;
+        for (int k = 0; k < ntiles; ++k) {
+            const bool has_next = k + 1 < ntiles;
+            for (int i0 = 0; i0 < n; i0 += 8) {
+                // interval i = i0 + j; i0 is a multiple of 8: every index below is a compile-time constant of j (a template argument,
+                // not an unrolled loop variable: the register sets must be split into registers before any loop pass runs)
+                auto ivl = [&](auto jt) {
+                    constexpr int j = decltype(jt)::value;
+                    PC_TR(1);
+                    tr_write((j + 1) & 1);
+                    if (!(SEAM_W24PC_ABL & 1)) {
+                        store_chunk(rq[((j + 3) >> 2) & 1], (j + 3) & 3, (j + 3) & 1);
+                        if ((j & 3) == 0) load_group(rq[((j + 3) >> 2) & 1]);
+                    }
+                    tr_read(j & 1);
+                    PC_TR(2);
+                    if (!(SEAM_W24PC_ABL & 8)) tr_math();
+                    PC_PIN_VA();
+                    // address state for the next tile, recomputed in this burst window right behind its last use
+                    if (j == 7 && i0 == n - 16) {           // i = n - 9: the request stage (last request of this tile: i = n - 12)
+                        if (has_next) {
+                            const PcGeo qn = pc_geo(p, tile + S);
+                            setup_patch(qn, lpn);
+                            rsrcL = x_desc(qn);
+                        } else {                            // no next tile: the requests fall outside every image
+#pragma unroll
+                            for (int r = 0; r < NP; ++r) goff[r] = kOob;
+                        }
+                        gL = 0;
+                    }
+                    if (j == 4 && i0 == n - 8 && has_next) {                                    // i = n - 4: the store stage
+#pragma unroll
+                        for (int r = 0; r < NP; ++r) lp[r] = lpn[r];
+                    }
+                    if (j == 5 && i0 == n - 8 && has_next) setup_read(pc_geo(p, tile + S));     // i = n - 3
+                    PC_TR(6);
+                    // the fragments are inputs of the barrier statement: hipcc otherwise sinks the packed ops below it
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::"v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(va[3]), "v"(va[4]), "v"(va[5]) : "memory");
+                    SB();
+                };
+                ivl(std::integral_constant<int, 0>{});
+                ivl(std::integral_constant<int, 1>{});
+                ivl(std::integral_constant<int, 2>{});
+                ivl(std::integral_constant<int, 3>{});
+                ivl(std::integral_constant<int, 4>{});
+                ivl(std::integral_constant<int, 5>{});
+                ivl(std::integral_constant<int, 6>{});
+                ivl(std::integral_constant<int, 7>{});
+            }
+            finish_prev(tile);                  // this tile's epilogue (the consumers are past their last chunk's barrier)
+            tile += S;
         }
+#undef PC_PIN_VA
+#undef PC_STORE12
+#undef PC_ST1
     } else {
-        // ================================================= consumer =================================================
-#pragma unroll
-        for (int nu = 0; nu < 6; ++nu)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nu][nt][r] = 0.f;
-#ifdef SEAM_W24PC_PRIO_C
-        __builtin_amdgcn_s_setprio(SEAM_W24PC_PRIO_C);
-#endif
-#ifdef SEAM_W24PC_AGPR       // experiment: an "a" constraint anywhere in the kernel makes hipcc select the AccVGPR form of the MFMAs
-#endif
-        const int ntile_bytes = p.nchunks * 24576;
-        const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((const char*)p.u + (size_t)tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
+        // =================================================== consumer ===================================================
+        f32x16 acc[6][NT];
+        const int ntile_bytes = n * 24576;
         int uoff0 = (xi * 6 * 64 + lane) * 16;
         f32x4 bq[RING][NT];                     // B fragments: slot j % RING holds position instance j = 6 * chunk + nu
         f32x4 aq[2];                            // A fragments: position nu in aq[nu & 1]
-        auto load_b = [&](int slot_, int nu, int chunk) {
-            const int so = chunk * 24576 + (nu >> 2) * 4096;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bq[slot_][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff0 + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
-                SB();
-            }
-        };
         auto read_a = [&](int buf, int nu) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + vlane + buf * PC_VB + nu * 1024); };
-#pragma unroll
-        for (int j = 0; j < RING; ++j) {        // in ring order, pinned: the K loop's vmcnt waits count on it
-            SB();
-            load_b(j, j % 6, j / 6);
-        }
-        SB();
         PC_BAR();                               // P1
         PC_BAR();                               // P2
         PC_BAR();                               // P3
-        aq[0] = read_a(0, 0);
-        // one chunk: positions 0..5 in order; c = chunk parity (V buffer), t = chunk index
-        auto chunk = [&](int t, const int c) {
+        int tile = tile0;
+        for (int k = 0; k < ntiles; ++k) {
+            const PcGeo q = pc_geo(p, tile);
+            const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const char*)p.u + (size_t)q.tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
+            auto load_b = [&](int slot_, int nu, int chunk) {
+                const int so = chunk * 24576 + (nu >> 2) * 4096;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int jl = 6 * c + i, sl = jl % RING;
-                SB();
-#ifdef SEAM_W24PC_TRACE_POS
-                PC_TR(10 + i);
-#endif
-                if (i < 5) aq[(i + 1) & 1] = read_a(c, i + 1);
-                SB();
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-#ifdef SEAM_W24PC_AGPR
-                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][nt]) : "v"(aq[i & 1][kk]), "v"(bq[sl][nt][kk]));
-#else
-                        acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i & 1][kk], bq[sl][nt][kk], acc[i][nt], 0, 0, 0);
-#endif
-                        SB();
-                    }
-                if (!(SEAM_W24PC_ABL & 2)) {
-                    const int j2 = jl + RING;                       // the instance that takes over this slot
-                    load_b(sl, j2 % 6, t - c + j2 / 6);
+                for (int nt = 0; nt < NT; ++nt) {
+                    bq[slot_][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff0 + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
+                    SB();
                 }
+            };
+#pragma unroll
+            for (int j = 0; j < RING; ++j) {    // in ring order, pinned: the K loop's vmcnt waits count on it
                 SB();
-                if (i == 4) {
-                    PC_TR(8);
-                    if (!(SEAM_W24PC_ABL & 4)) PC_BAR();
-                    PC_TR(9);
-                    aq[0] = read_a(c ^ 1, 0);
-                }
+                load_b(j, j % 6, j / 6);
             }
-        };
-        static_assert(12 % RING == 0, "the ring's phase repeats every two chunks");
-        for (int t = 0; t < p.nchunks; t += 2) {
-            asm volatile("" : "+v"(uoff0));
-            chunk(t, 0);
-            chunk(t + 1, 1);                    // nchunks is even (wino24_pc): one straight two-chunk body, exact vmcnt waits
+            SB();
+            aq[0] = read_a(0, 0);
+            // one chunk: positions 0..5 in order; c = chunk parity (V buffer), t = chunk index; FIRST: the tile's first chunk
+            // multiplies its first k-step into a zero constant instead of clearing 192 accumulators
+            auto chunk = [&](const int t, const int c, const bool first) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int jl = 6 * c + i, sl = jl % RING;
+                    SB();
+#ifdef SEAM_W24PC_TRACE_POS
+                    PC_TR(10 + i);
+#endif
+                    if (i < 5) aq[(i + 1) & 1] = read_a(c, i + 1);
+                    SB();
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            if (first && kk == 0) {
+                                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i & 1][kk], bq[sl][nt][kk], z, 0, 0, 0);
+                            } else {
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i & 1][kk], bq[sl][nt][kk], acc[i][nt], 0, 0, 0);
+                            }
+                            SB();
+                        }
+                    if (!(SEAM_W24PC_ABL & 2)) {
+                        const int j2 = jl + RING;                   // the instance that takes over this slot (chunks past the end:
+                        load_b(sl, j2 % 6, t - c + j2 / 6);         // the next n-tile's data or zero fill, never used)
+                    }
+                    SB();
+                    if (i == 4) {
+                        PC_TR(8);
+                        PC_BAR();
+                        PC_TR(9);
+                        aq[0] = read_a(c ^ 1, 0);
+                    }
+                }
+            };
+            static_assert(12 % RING == 0, "the ring's phase repeats every two chunks");
+            chunk(0, 0, true);
+            chunk(1, 1, false);
+            for (int t = 2; t < n; t += 2) {
+                asm volatile("" : "+v"(uoff0));
+                chunk(t, 0, false);
+                chunk(t + 1, 1, false);         // nchunks is even (wino24_pc): one straight two-chunk body, exact vmcnt waits
+            }
+            // ---- epilogue: the nu half of the output transform (A4t: 6 -> 4) on register pairs into the exchange array ----
+            //   columns (A4t over nu): Y0 = m0+m1+m2+m3+m4, Y1 = (m1-m2) + 2(m3-m4), Y2 = (m1+m2) + 4(m3+m4), Y3 = (m1-m2) + 8(m3-m4) + m5
+            //   rows (A2t over xi, across the waves, in pc_finish): y0 = q0+q1+q2, y1 = q1-q2-q3
+            PcEpi epi;
+            pc_epi_vectors(p, q, tid, epi);     // requested here, used behind the first epilogue barrier
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                PC_TR(20 + 4 * nt);
+                if (nt == 1) PC_BAR();          // E2: the finishers of n-tile 0 are done with ex
+                PC_TR(21 + 4 * nt);
+                if (!(SEAM_W24PC_ABL & 16)) {
+                    const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) {
+                        auto rd = [&](int nu) -> f32x2 { return f32x2{acc[nu][nt][2 * h], acc[nu][nt][2 * h + 1]}; };
+                        const f32x2 m0 = rd(0), m1 = rd(1), m2 = rd(2), m3 = rd(3), m4 = rd(4), m5 = rd(5);
+                        const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
+                        const f32x2 y0 = pk_add(pk_add(m0, s12), s34);
+                        const f32x2 y1 = pk_fma_s(c2, d34, d12);
+                        const f32x2 y2 = pk_fma_s(c4, s34, s12);
+                        const f32x2 y3 = pk_add(pk_fma_s(c8, d34, d12), m5);
+                        const int r = 2 * h;
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        float* e0 = &ex[((xi * 4 + 0) * 32 + row) * 32 + (lane & 31)];
+                        e0[0] = y0[0];               e0[32] = y0[1];
+                        e0[1024] = y1[0];            e0[1024 + 32] = y1[1];
+                        e0[2048] = y2[0];            e0[2048 + 32] = y2[1];
+                        e0[3072] = y3[0];            e0[3072 + 32] = y3[1];
+                    }
+                } else if (nt == 1) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+                        for (int m = 0; m < NT; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sum += acc[nu][m][r];
+                    if (sum == 123456.789f) p.y[tid] = sum;
+                }
+                PC_TR(22 + 4 * nt);
+                PC_BAR();                       // E1 / E3: ex holds this n-tile
+                PC_TR(23 + 4 * nt);
+                if (!(SEAM_W24PC_ABL & 16)) pc_finish(p, q, ex, nt, tid, true, epi);
+            }
+            tile += S;
         }
     }
 #undef SB
-
-    // ---- epilogue (v1): the consumers' 256 threads run the epilogue of conv3x3_wino24<2>; the producers keep the barriers company
-    if (SEAM_W24PC_ABL & 16) {
-        if (consumer) {
-            float sum = 0.f;
-#pragma unroll
-            for (int nu = 0; nu < 6; ++nu)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum += acc[nu][nt][r];
-            if (sum == 123456.789f) p.y[tid] = sum;
-        }
-        return;
-    }
-    const size_t out_img = (size_t)p.Ho * p.Wo * p.K * 4;
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((char*)p.y + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)(p.res ? p.res : p.y) + (size_t)n_img * out_img), 0, (int)(out_img * n_here), 0x00020000);
-    const int et = (tid & 255) >> 3;
-    const int n4 = tid & 7;
-    int g, tyt, txt, prow_unused;
-    const bool tile_ok = slot(et, g, tyt, txt, prow_unused) && g < n_here;
-    const int oy = 2 * tyt, ox = 4 * txt;
-    const int cstep = p.K * 4, rstep = p.Wo * cstep;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int ncol = (tn * NT + nt) * 32 + n4 * 4;
-        PC_BAR();                     // previous readers of `ex` (first pass: of the raw / V buffers it aliases) are done
-        if (consumer) {
-            const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                auto rd = [&](int nu) -> f32x2 { return f32x2{acc[nu][nt][2 * h], acc[nu][nt][2 * h + 1]}; };
-                const f32x2 m0 = rd(0), m1 = rd(1), m2 = rd(2), m3 = rd(3), m4 = rd(4), m5 = rd(5);
-                const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
-                const f32x2 y0 = pk_add(pk_add(m0, s12), s34);
-                const f32x2 y1 = pk_fma_s(c2, d34, d12);
-                const f32x2 y2 = pk_fma_s(c4, s34, s12);
-                const f32x2 y3 = pk_add(pk_fma_s(c8, d34, d12), m5);
-                const int r = 2 * h;
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float* e0 = &ex[((xi * 4 + 0) * 32 + row) * 32 + (lane & 31)];
-                e0[0] = y0[0];               e0[32] = y0[1];
-                e0[1024] = y1[0];            e0[1024 + 32] = y1[1];
-                e0[2048] = y2[0];            e0[2048 + 32] = y2[1];
-                e0[3072] = y3[0];            e0[3072 + 32] = y3[1];
-            }
-        }
-        PC_BAR();
-        // second half: the 16 (output column, row) pieces of a tile are split between the two wave groups: consumers take the
-        // output columns 0, 1, producers 2, 3 -- 512 threads store instead of 256
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + ncol);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + ncol);
-        const unsigned obase = (unsigned)(((g * p.Ho + oy) * p.Wo + ox) * p.K + ncol) * 4u;
-#pragma unroll
-        for (int bc = 0; bc < 2; ++bc) {
-            const int bcol = (consumer ? 0 : 2) + bc;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(&ex[((1 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
-            const f32x4 q2 = *reinterpret_cast<const f32x4*>(&ex[((2 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
-            const f32x4 q3 = *reinterpret_cast<const f32x4*>(&ex[((3 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
-            f32x4 yv[2];
-            yv[0] = q0 + q1 + q2;
-            yv[1] = q1 - q2 - q3;
-#pragma unroll
-            for (int aa = 0; aa < 2; ++aa) {
-                const bool ok = tile_ok && (oy + aa) < p.Ho && (ox + bcol) < p.Wo;
-                const unsigned off = ok ? obase + (unsigned)(aa * rstep + bcol * cstep) : kOob;
-                f32x4 v = yv[aa] * sc + sh;
-                if (p.res) {
-                    const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
-                    if (p.relu == 2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
-                    } else {
-                        v += rv;
-                    }
-                }
-                if (p.relu == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, off, 0, 0);
-            }
-        }
-    }
-}
-
-#ifndef SEAM_W24PC_RING
-#define SEAM_W24PC_RING 4
-#endif
-
-__global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_pc[];
-    const int nblk = gridDim.x;
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int q8 = nblk >> 3, rem8 = nblk & 7;
-    const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
-    const int tm = fdiv(tile, p.tiles_n, p.m_tiles_n);
-    const int tn = tile - tm * p.tiles_n;
-    const int per_img = p.per_img;
-    const int tm_img = fdiv(tm, per_img, p.m_per_img);
-    int rb = tm - tm_img * per_img;
-    int reg = 0;
-    if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
-        rb -= p.bx[0] * p.by[0];
-        reg = 1;
-        if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
-    }
-    const int hs = (p.TX[reg] + 1) | 1;
-    if (hs == 9) w24pc_block<9, SEAM_W24PC_RING>(p, smem_pc, reg, rb, tm, tn, tm_img);
-    else if (hs == 3) w24pc_block<3, SEAM_W24PC_RING>(p, smem_pc, reg, rb, tm, tn, tm_img);
-    else if (hs == 5) w24pc_block<5, SEAM_W24PC_RING>(p, smem_pc, reg, rb, tm, tn, tm_img);
-    else w24pc_block<0, SEAM_W24PC_RING>(p, smem_pc, reg, rb, tm, tn, tm_img);
 }
 
 // OIHW fp32 [K, Cin, 3, 3] -> U = G2 g G4t in MFMA fragment order: [K/32][Cstore/8][24][64][4]
@@ -1242,7 +1373,7 @@ inline int wino24_nsplit(int C, int K, long patch_blocks) {
 // the producer / consumer kernel takes the NT = 2 launches (SEAM_W24_PC=0: conv3x3_wino24<2>, the round-4 kernel, stays selectable)
 inline bool wino24_pc(const Wino24Args& a) {
     static const int want = getenv("SEAM_W24_PC") ? atoi(getenv("SEAM_W24_PC")) : 1;
-    return want && a.nt == 2 && a.nsplit == 1 && a.nchunks >= 2 && a.nchunks % 2 == 0;
+    return want && a.nt == 2 && a.nsplit == 1 && a.nchunks >= 16 && a.nchunks % 8 == 0;
 }
 
 int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long& blocks) {
@@ -1333,37 +1464,47 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
     a.x = x; a.u = u_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.relu = relu;
     a.trace = nullptr;
+    a.total_tiles = 0;
     static const int dyn = getenv("SEAM_W24_DYNLDS") ? atoi(getenv("SEAM_W24_DYNLDS")) : 0;     // dev knob: occupancy experiments
     if (wino24_pc(a)) {
         // > 64 KiB of dynamic LDS needs the attribute once per device (an atomic flag per device: the ABI is thread-safe per stream)
         static std::atomic<unsigned> attr_done{0};
+        static std::atomic<int> cus[32];
         int dev = 0;
         (void)hipGetDevice(&dev);
         const unsigned bit = 1u << (dev & 31);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino24pc, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
+            const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino24pc<SEAM_W24PC_RING>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
             if (e != hipSuccess) return (int)e;
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+            cus[dev & 31].store(ncu, std::memory_order_relaxed);
             attr_done.fetch_or(bit, std::memory_order_release);
         }
+        // persistent grid: one block per CU walks its XCD's tile range (SEAM_W24_PERSIST=0: one tile per block)
+        static const int persist = getenv("SEAM_W24_PERSIST") ? atoi(getenv("SEAM_W24_PERSIST")) : 1;
+        a.total_tiles = (int)blocks;
+        const int ncu = cus[dev & 31].load(std::memory_order_relaxed);
+        const unsigned grid = (unsigned)(persist && blocks > ncu ? ncu : blocks);
 #ifdef SEAM_W24PC_TRACE
         static unsigned long long* tbuf = nullptr;
-        if (!tbuf) hipMalloc((void**)&tbuf, 8 * 4096 * 8);
-        hipMemset(tbuf, 0, 8 * 4096 * 8);
+        if (!tbuf) (void)hipMalloc((void**)&tbuf, 8 * 4096 * 8);
+        (void)hipMemset(tbuf, 0, 8 * 4096 * 8);
         a.trace = tbuf;
 #endif
-        hipLaunchKernelGGL(conv3x3_wino24pc, dim3((unsigned)blocks), dim3(512), PC_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(conv3x3_wino24pc<SEAM_W24PC_RING>, dim3(grid), dim3(512), PC_LDS, (hipStream_t)stream, a);
 #ifdef SEAM_W24PC_TRACE
         {
             static int dumped = 0;
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
             if (dumped++ == 3) {
                 static unsigned long long h[8 * 4096];
-                hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
                 for (int w = 0; w < 8; w += 4) {
                     unsigned long long prev = 0;
                     for (int k = 0; k < 4096 && h[w * 4096 + k]; ++k) {
                         const unsigned long long v = h[w * 4096 + k], tm = v & 0x00ffffffffffffffull;
-                        if (k >= 0) fprintf(stderr, "TR wave %d k %d tag %d t %llu d %lld\n", w, k, (int)(v >> 56), tm, prev ? (long long)(tm - prev) : 0ll);
+                        fprintf(stderr, "TR wave %d k %d tag %d t %llu d %lld\n", w, k, (int)(v >> 56), tm, prev ? (long long)(tm - prev) : 0ll);
                         prev = tm;
                     }
                 }
