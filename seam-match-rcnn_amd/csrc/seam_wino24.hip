@@ -675,6 +675,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
 #ifndef SEAM_W24PC_RING
 #define SEAM_W24PC_RING 4
 #endif
+#ifndef SEAM_W24PC_AD
+#define SEAM_W24PC_AD 1
+#endif
 constexpr int PC_VB = 4 * 6 * 64 * 16;                 // bytes per V buffer
 constexpr int PC_RAW = 0, PC_V = 2 * RAWB, PC_EX = 2 * RAWB + 2 * PC_VB;      // LDS map: raw[2] | V[2] | ex
 constexpr int PC_EXB = 4 * 4 * 32 * 32 * 4;
@@ -1028,7 +1031,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                 auto ivl = [&](auto jt) {
                     constexpr int j = decltype(jt)::value;
                     PC_TR(1);
+#ifdef SEAM_W24PC_PSLEEP
+                    __builtin_amdgcn_s_sleep(SEAM_W24PC_PSLEEP);
+#endif
                     tr_write((j + 1) & 1);
+#ifdef SEAM_W24PC_PSLEEP
+                    __builtin_amdgcn_s_sleep(SEAM_W24PC_PSLEEP);
+#endif
                     if (!(SEAM_W24PC_ABL & 1)) {
                         store_chunk(rq[((j + 3) >> 2) & 1], (j + 3) & 3, (j + 3) & 1);
                         if ((j & 3) == 0) load_group(rq[((j + 3) >> 2) & 1]);
@@ -1080,7 +1089,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         const int ntile_bytes = n * 24576;
         int uoff0 = (xi * 6 * 64 + lane) * 16;
         f32x4 bq[RING][NT];                     // B fragments: slot j % RING holds position instance j = 6 * chunk + nu
-        f32x4 aq[2];                            // A fragments: position nu in aq[nu & 1]
+        constexpr int AD = SEAM_W24PC_AD;       // A fragments are requested AD positions ahead of their MFMAs
+        f32x4 aq[AD + 1];                       // A fragments: position nu in aq[nu % (AD + 1)]
+        static_assert(6 % (AD + 1) == 0 && AD >= 1 && AD <= 2, "the fragment ring's phase repeats every chunk");
         auto read_a = [&](int buf, int nu) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + vlane + buf * PC_VB + nu * 1024); };
         PC_BAR();                               // P1
         PC_BAR();                               // P2
@@ -1104,7 +1115,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                 load_b(j, j % 6, j / 6);
             }
             SB();
-            aq[0] = read_a(0, 0);
+#pragma unroll
+            for (int a = 0; a < AD; ++a) aq[a] = read_a(0, a);
             // one chunk: positions 0..5 in order; c = chunk parity (V buffer), t = chunk index; FIRST: the tile's first chunk
             // multiplies its first k-step into a zero constant instead of clearing 192 accumulators
             auto chunk = [&](const int t, const int c, const bool first) {
@@ -1115,7 +1127,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
 #ifdef SEAM_W24PC_TRACE_POS
                     PC_TR(10 + i);
 #endif
-                    if (i < 5) aq[(i + 1) & 1] = read_a(c, i + 1);
+                    // the fragment AD positions ahead (the next chunk's first ones come from the other V buffer, behind the barrier)
+                    aq[(i + AD) % (AD + 1)] = i + AD < 6 ? read_a(c, i + AD) : read_a(c ^ 1, i + AD - 6);
                     SB();
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
@@ -1123,9 +1136,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                         for (int nt = 0; nt < NT; ++nt) {
                             if (first && kk == 0) {
                                 const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i & 1][kk], bq[sl][nt][kk], z, 0, 0, 0);
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i % (AD + 1)][kk], bq[sl][nt][kk], z, 0, 0, 0);
                             } else {
-                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i & 1][kk], bq[sl][nt][kk], acc[i][nt], 0, 0, 0);
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i % (AD + 1)][kk], bq[sl][nt][kk], acc[i][nt], 0, 0, 0);
                             }
                             SB();
                         }
@@ -1134,11 +1147,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                         load_b(sl, j2 % 6, t - c + j2 / 6);         // the next n-tile's data or zero fill, never used)
                     }
                     SB();
-                    if (i == 4) {
-                        PC_TR(8);
+                    if (i == 5 - AD) {          // every fragment of this chunk is in registers (or on its way, waited for by the barrier
+                        PC_TR(8);               // statement): the producers may overwrite V[c]
                         PC_BAR();
                         PC_TR(9);
-                        aq[0] = read_a(c ^ 1, 0);
                     }
                 }
             };
@@ -1361,7 +1373,10 @@ inline int wino24_nt(int K, int C, long blocks_nt1) {
     static const int force = getenv("SEAM_W24_NT") ? atoi(getenv("SEAM_W24_NT")) : 0;
     if (K % 64) return 1;
     if (force == 1 || force == 2) return force;
-    return (C >= 256 && blocks_nt1 / 2 >= 1024) ? 2 : 1;
+    // round 5: on the producer / consumer kernel the shorter K loop of the C = 128 layers pays as well (80 x 100^2 x 128: -6 %)
+    static const int pc = getenv("SEAM_W24_PC") ? atoi(getenv("SEAM_W24_PC")) : 1;
+    const int cmin = pc && C % 64 == 0 ? 128 : 256;
+    return (C >= cmin && blocks_nt1 / 2 >= 1024) ? 2 : 1;
 }
 
 // XCD groups the n-tiles are split over (1 = every XCD walks all n-tiles of its patches).  Default off until measured per shape.

@@ -171,6 +171,75 @@ assert worst < 2e-5, worst
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+_PC_CHILD = r'''
+import hashlib, math, sys, torch
+import seam_match_rcnn_amd.ops as ops
+import seam_match_rcnn_amd.synth as synth
+from seam_match_rcnn_amd import _native
+ops.WINO_MIN_FILL = 0
+d = torch.device("cuda:0")
+lib = _native.lib()
+# N, C, H, W, K, pad, residual mode (0 none, 1 add, 2 ReLU mask), relu, scale
+CASES = [(8, 256, 96, 88, 256, 1, 0, 1, True),       # main region + right strip + bottom strip, FrozenBN scale
+         (24, 256, 50, 50, 256, 1, 1, 1, False),     # residual add
+         (640, 256, 14, 14, 256, 1, 0, 1, False),    # stacked mode (maps narrower than a block), ROI-sized
+         (640, 256, 12, 12, 256, 0, 0, 1, False),    # valid convolution (the match trunk)
+         (16, 128, 100, 100, 128, 1, 0, 1, True),    # the short K loop (16 chunks)
+         (48, 512, 25, 25, 512, 1, 0, 0, False),     # 64 chunks, no ReLU
+         (40, 256, 77, 91, 64, 1, 2, 0, False),      # one n-tile pair, ReLU-mask epilogue, ragged map
+         (4, 256, 200, 200, 128, 1, 0, 1, True)]     # many tiles per block (persistent walk), two n-tile pairs
+for (n, c, h, w, k, pad, res, relu, bn) in CASES:
+    x = torch.from_numpy(synth.normal(synth.stream_id(5, "x"), (n, h, w, c))).to(d)
+    wt = torch.from_numpy(synth.normal(synth.stream_id(6, "w"), (k, c, 3, 3))).to(d) / math.sqrt(9 * c)
+    bias = torch.from_numpy(synth.normal(synth.stream_id(7, "b"), (k,))).to(d)
+    bnp = None
+    if bn:
+        bnp = (torch.from_numpy(synth.uniform(synth.stream_id(8, "g"), (k,))).to(d) + 0.5, bias, bias * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(9, "v"), (k,))).to(d) + 0.5)
+    pc = ops.pack_conv(wt, None, bnp, stride=1, pad=pad) if bn else ops.pack_conv(wt, bias, stride=1, pad=pad)
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    r = torch.from_numpy(synth.normal(synth.stream_id(10, "r"), (n, ho, wo, k))).to(d) if res else None
+    mode = 2 if res == 2 else bool(relu)
+    ops.WINOGRAD, ops.WINOGRAD24 = True, 2
+    a = ops.conv2d(x, pc, mode, r)
+    a2 = ops.conv2d(x, pc, mode, r)
+    assert torch.equal(a, a2), "repeat launches differ"
+    ops.WINOGRAD = False
+    b = ops.conv2d(x, pc, mode, r)
+    form = lib.seam_wino24_form(n, h, w, c, k, pad)
+    print("CASE", n, c, h, w, k, pad, res, "form", form, "sha", hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest(),
+          "err", float((a - b).abs().max()) / float(b.abs().max()))
+'''
+
+
+def _run_pc_child(env_extra):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _PC_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rows = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("CASE")]
+    assert len(rows) == 8, r.stdout[-2000:]
+    return rows
+
+
+def test_wino24_producer_consumer_kernel():
+    """conv3x3_wino24pc (round 5: the NT = 2 block as MFMA-only consumer waves + transform / load producer waves, persistent over
+    its XCD's tiles) on layer shapes that exercise every branch of it -- three-region maps, stacked maps, valid convolution, both
+    K-loop lengths, every epilogue mode, many tiles per block: within 2e-5 of the exact implicit GEMM, repeat launches identical,
+    and BIT-IDENTICAL to conv3x3_wino24<2> (SEAM_W24_PC=0, the round-4 kernel) and to its own one-tile-per-block launch
+    (SEAM_W24_PERSIST=0): the three compute the same fma chains."""
+    pc = _run_pc_child({})
+    r4 = _run_pc_child({"SEAM_W24_PC": "0"})
+    one = _run_pc_child({"SEAM_W24_PERSIST": "0"})
+    for a, b, c in zip(pc, r4, one):
+        assert a[1:8] == b[1:8] == c[1:8]
+        assert a[9] == "1" and b[9] == "0" and c[9] == "1", (a, b, c)       # the launcher really took the kernel under test
+        assert float(a[13]) < 2e-5 and float(b[13]) < 2e-5, (a, b)
+        assert a[11] == b[11] == c[11], ("results differ between the kernels", a, b, c)
+
+
 def test_full_size_layers_against_the_exact_kernel(ops):
     """BASELINE-size layers (one clip's 10 frames at 200^2 x 256 channels) through the kernels the bench uses -- F(2x4)
     Winograd for the 3x3, the row-stream kernel for the 15 RPN outputs -- against the exact implicit GEMM on the same inputs
