@@ -211,7 +211,7 @@ def batched_nms(boxes, scores, idxs, thr):
 
 
 def rpn_filter_proposals(objectness, deltas, anchors, image_sizes, pre_nms_top_n=1000,
-                         post_nms_top_n=1000, nms_thresh=0.7, min_size=1e-3):
+                         post_nms_top_n=1000, nms_thresh=0.7, min_size=1e-3, return_index=False):
     """RegionProposalNetwork.filter_proposals (eval).  objectness: list per level
     [N,A,H,W]; deltas: list per level [N,4A,H,W]; anchors: list per level [HWA,4]."""
     n = objectness[0].shape[0]
@@ -221,7 +221,7 @@ def rpn_filter_proposals(objectness, deltas, anchors, image_sizes, pre_nms_top_n
     anc = torch.cat(anchors, 0)
     per_level = [a.shape[0] for a in anchors]
     levels = torch.cat([torch.full((c,), i, dtype=torch.int64) for i, c in enumerate(per_level)])
-    results, result_scores = [], []
+    results, result_scores, result_index = [], [], []
     for b in range(n):
         props = decode_boxes(dl[b], anc)
         idx, off = [], 0
@@ -236,10 +236,13 @@ def rpn_filter_proposals(objectness, deltas, anchors, image_sizes, pre_nms_top_n
         bx = clip_boxes(props[idx], image_sizes[b])
         lv = levels[idx]
         keep = small_box_keep(bx, min_size)
-        bx, sc, lv = bx[keep], sc[keep], lv[keep]
+        bx, sc, lv, idx = bx[keep], sc[keep], lv[keep], idx[keep]
         keep = batched_nms(bx, sc, lv, nms_thresh)[:post_nms_top_n]
         results.append(bx[keep])
         result_scores.append(sc[keep])
+        result_index.append(idx[keep])
+    if return_index:        # tests only: the flat anchor index (level-major, then y, x, anchor) of every kept proposal
+        return results, result_scores, result_index
     return results, result_scores
 
 

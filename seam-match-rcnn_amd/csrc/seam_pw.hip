@@ -25,6 +25,7 @@
 // Tiles are dealt XCD-aware: row tile t lives on XCD t mod 8, and the K / NS slab groups of one XCD walk the same row tiles at
 // about the same time, so an activation row is read from HBM once and from that XCD's L2 by the other slabs.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -283,7 +284,9 @@ inline int pw_config(int M, int C1, int C2, int K) {
     const int Ct = C1 + C2;
     if (M <= 0 || C1 <= 0 || (C1 % 32) || C2 < 0 || (C2 % 32) || Ct > 256 || K <= 0 || (K % 64)) return 0;
     const long room = 163840 - PW_WAVES * TBUF;
-    if (K % 256 == 0 && 256l * (Ct * 4 + 16) <= room) return 108;
+    // every branch needs its slab count ns = K / (32 * NT) to divide 32: the block -> (slab, row group) decode walks ns slabs inside
+    // each XCD's 32 blocks; other K (768, 8448, ...) are not served here and stay on the implicit GEMM
+    if (K % 256 == 0 && 256l * (Ct * 4 + 16) <= room && 32 % (K / 256) == 0) return 108;
     if (K % 128 == 0 && 128l * (Ct * 4 + 16) <= room && 32 % (K / 128) == 0) return 204;
     if (32 % (K / 64) == 0) return 202;
     return 0;
@@ -322,19 +325,22 @@ int seam_conv1x1_sw_f32(const float* x, const float* x2, const float* w, const f
     // one block per CU; fewer when the rows do not fill them (a block's first act is to copy its slab): blocks per slab = row
     // tiles / 8 waves, rounded up to the 8 XCDs.  The grid never changes a result (each output pixel is one wave's fixed fma chain).
     static const int max_blk = getenv("SEAM_PW_BLOCKS") ? atoi(getenv("SEAM_PW_BLOCKS")) : 256;      // dev knob; a multiple of 64
+    if (max_blk < 64 || max_blk % 64 || max_blk < 8 * a.ns) return (int)hipErrorInvalidValue;
     const int tiles = (M + 32 * MT - 1) / (32 * MT);
     int per_slab = (((tiles + PW_WAVES - 1) / PW_WAVES + 7) / 8) * 8;
-    if (per_slab > max_blk / a.ns) per_slab = max_blk / a.ns;
+    if (per_slab > max_blk / a.ns) per_slab = (max_blk / a.ns) & ~7;      // a multiple of 8 (one row group per XCD), >= 8 by the check above
     const int nblk = per_slab * a.ns;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
 #define SEAM_PW_LAUNCH(mt, nt, dual, res)                                                                                         \
     do {                                                                                                                         \
-        static bool attr_done = false;                                                                                           \
-        if (!attr_done) {                                                                                                        \
+        static std::atomic<unsigned> attr_done{0};      /* one bit per device: the ABI is thread-safe per stream */               \
+        int dev_ = 0;                                                                                                            \
+        (void)hipGetDevice(&dev_);                                                                                               \
+        if (!(attr_done.load(std::memory_order_acquire) & (1u << (dev_ & 31)))) {                                                \
             e = hipFuncSetAttribute((const void*)pw_sw_kernel<mt, nt, dual, res>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                     163840);                                                                                     \
-            attr_done = e == hipSuccess;                                                                                         \
+            if (e == hipSuccess) attr_done.fetch_or(1u << (dev_ & 31), std::memory_order_release);                               \
         }                                                                                                                        \
         if (e == hipSuccess) hipLaunchKernelGGL((pw_sw_kernel<mt, nt, dual, res>), dim3(nblk), dim3(64 * PW_WAVES), lds, st, a); \
     } while (0)

@@ -910,6 +910,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
 
         __amdgpu_buffer_rsrc_t rsrcL;
         int gL = 0;                             // next group (of its tile) the load stage requests
+        // The request stage runs two groups (eight chunks) ahead of the store stage: with n = 8 chunks per tile (the C = 64 layers) it
+        // works one whole tile ahead of the others (LEAD = 1), otherwise it moves to the next tile eight intervals before the end.
+        const int LEAD = n == 8 ? 1 : 0;
+        const int i_setup = n == 8 ? 6 : n - 9; // the interval in whose burst window the request stage's next address set is computed
         {
             const PcGeo q0 = pc_geo(p, tile0);
             setup_patch(q0, lp);
@@ -985,6 +989,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         // ---- prologue of the block's first tile: V(0) in LDS, V(1) in registers, raw(2) in LDS, chunk 3 in registers, group 1 in flight
         load_group(rq[0]);
         load_group(rq[1]);
+        if (LEAD) {                             // n = 8: both groups of the first tile are requested; the stage moves on to the block's second tile
+            if (ntiles > 1) {
+                const PcGeo q1 = pc_geo(p, tile0 + S);
+                setup_patch(q1, lpn);
+                rsrcL = x_desc(q1);
+            } else {
+#pragma unroll
+                for (int r = 0; r < NP; ++r) goff[r] = kOob;
+            }
+            gL = 0;
+        }
         store_chunk(rq[0], 0, 0);
         store_chunk(rq[0], 1, 1);
         PC_BAR();                               // P1: raw(0), raw(1) visible (the patch is shared by the four producer waves)
@@ -1024,7 +1039,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         };
         int tile = tile0;
         for (int k = 0; k < ntiles; ++k) {
-            const bool has_next = k + 1 < ntiles;
+            const bool has_next = k + 1 < ntiles, has_lead = k + 1 + LEAD < ntiles;
             for (int i0 = 0; i0 < n; i0 += 8) {
                 // interval i = i0 + j; i0 is a multiple of 8: every index below is a compile-time constant of j (a template argument,
                 // not an unrolled loop variable: the register sets must be split into registers before any loop pass runs)
@@ -1047,9 +1062,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                     if (!(SEAM_W24PC_ABL & 8)) tr_math();
                     PC_PIN_VA();
                     // address state for the next tile, recomputed in this burst window right behind its last use
-                    if (j == 7 && i0 == n - 16) {           // i = n - 9: the request stage (last request of this tile: i = n - 12)
-                        if (has_next) {
-                            const PcGeo qn = pc_geo(p, tile + S);
+                    if ((j == 7 || j == 6) && i0 + j == i_setup) {      // the request stage (n >= 16: its last request for this tile was at i = n - 12)
+                        if (has_lead) {
+                            const PcGeo qn = pc_geo(p, tile + (1 + LEAD) * S);
                             setup_patch(qn, lpn);
                             rsrcL = x_desc(qn);
                         } else {                            // no next tile: the requests fall outside every image
@@ -1373,9 +1388,9 @@ inline int wino24_nt(int K, int C, long blocks_nt1) {
     static const int force = getenv("SEAM_W24_NT") ? atoi(getenv("SEAM_W24_NT")) : 0;
     if (K % 64) return 1;
     if (force == 1 || force == 2) return force;
-    // round 5: on the producer / consumer kernel the shorter K loop of the C = 128 layers pays as well (80 x 100^2 x 128: -6 %)
+    // round 5: on the producer / consumer kernel the shorter K loops of the C = 64 / 128 layers pay as well (80 x 100^2 x 128: -6 %)
     static const int pc = getenv("SEAM_W24_PC") ? atoi(getenv("SEAM_W24_PC")) : 1;
-    const int cmin = pc && C % 64 == 0 ? 128 : 256;
+    const int cmin = pc && C % 64 == 0 ? 64 : 256;
     return (C >= cmin && blocks_nt1 / 2 >= 1024) ? 2 : 1;
 }
 
@@ -1388,7 +1403,7 @@ inline int wino24_nsplit(int C, int K, long patch_blocks) {
 // the producer / consumer kernel takes the NT = 2 launches (SEAM_W24_PC=0: conv3x3_wino24<2>, the round-4 kernel, stays selectable)
 inline bool wino24_pc(const Wino24Args& a) {
     static const int want = getenv("SEAM_W24_PC") ? atoi(getenv("SEAM_W24_PC")) : 1;
-    return want && a.nt == 2 && a.nsplit == 1 && a.nchunks >= 16 && a.nchunks % 8 == 0;
+    return want && a.nt == 2 && a.nsplit == 1 && a.nchunks >= 8 && a.nchunks % 8 == 0;
 }
 
 int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long& blocks) {

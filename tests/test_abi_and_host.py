@@ -48,6 +48,16 @@ def test_host_helpers_no_gpu(native):
     assert lib.seam_conv_kred(256, 3, 3) == 2304 and lib.seam_conv_kred(4, 7, 7) == 224
     assert lib.seam_conv_rows_padded(15) == 64 and lib.seam_conv_rows_padded(256) == 256
     assert lib.seam_nlb_workspace_floats(2, 10) >= 2 * 10 * 130
+    # the weights-stationary pointwise kernel only takes output-channel counts whose slab count divides an XCD's 32 blocks (ADVICE r4:
+    # K = 768 would have redone tiles, K = 8448 left channels unwritten / hung): other K stay on the implicit GEMM
+    cfg = lambda c, k: lib.seam_conv1x1_sw_config(1 << 20, c, 0, k)
+    assert cfg(64, 256) == 108 and cfg(128, 512) == 108 and cfg(256, 1024) == 204 and cfg(256, 64) == 202 and cfg(64, 2048) == 108
+    assert cfg(64, 768) == 0 and cfg(64, 8448) == 0 and cfg(256, 768) == 0 and cfg(512, 256) == 0 and cfg(64, 96) == 0
+    # layer shapes the launcher gives to the producer / consumer Winograd kernel (round 5) and those it must not
+    assert lib.seam_wino24_form(80, 200, 200, 256, 256, 1) == 1 and lib.seam_wino24_form(80, 100, 100, 128, 128, 1) == 1
+    assert lib.seam_wino24_form(80, 200, 200, 64, 64, 1) == 1 and lib.seam_wino24_form(80, 13, 13, 256, 256, 1) == 0
+    assert lib.seam_wino24_form(80, 200, 200, 32, 64, 1) == 0 and lib.seam_wino24_form(80, 200, 200, 64, 32, 1) == 0
+    assert lib.seam_wino24_form(2, 20, 20, 256, 256, 1) == 0 and lib.seam_wino24_form(1, 8, 8, 7, 32, 1) == -1
 
 
 def test_product_path_fails_loudly_without_gpu(native):

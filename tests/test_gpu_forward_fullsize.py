@@ -7,6 +7,8 @@ printed list of at most ONE near-tie flip per side (tests/parity_sets.py: the ob
 observed + 1); descriptors / ROI features / masks of the paired detections within the north_star tolerance (1e-3 of scale).
 Frames: two synthetic 800x800 seeds and one 1080x1920 frame (resized to 750x1333, padded 768x1344: 257 796 anchors -- the
 geometry of BASELINE configs[4])."""
+import math
+
 import pytest
 import torch
 
@@ -17,15 +19,34 @@ from parity_sets import assert_same_set
 from test_gpu_ops import assert_close
 
 
-def assert_same_order(partner, what, max_moved=16, max_shift=2):
-    """Both lists are sorted by objectness: the device list is the reference list up to LOCAL swaps of near-tied neighbours (two
-    XX
-    positions, each by one place; gate: at most `max_moved` positions, none displaced by more than `max_shift`."""
+def assert_same_order(partner, what, ref_logit, noise, max_moved=16, max_shift=2):
+    """Both lists are sorted by objectness.  Order is defined by score, ties are not: the device list may differ from the reference
+    list only where two members' REFERENCE logits are closer than the two implementations' own disagreement on a logit (`noise` =
+    max |device logit - reference logit| over every anchor of the frame, two exact-fp32 chains through ~50 layers; a pair further
+    apart than 2 x noise cannot legitimately swap).  Every inverted pair is checked against that bound and the worst one printed, in
+    units of the bound and in ulps of the logit; the absolute caps (<= max_moved positions, none displaced by more than max_shift)
+    stay as a backstop only.  `partner[i]` = device position of reference member i (-1: flipped out, judged by assert_same_set)."""
     ok = partner >= 0
-    disp = (partner[ok] - torch.arange(len(partner))[ok]).abs()
+    pos = torch.arange(len(partner))
+    disp = (partner[ok] - pos[ok]).abs()
     moved = int((disp > 0).sum())
-    print(f"[{what}] order: {moved} of {len(partner)} positions moved, largest displacement {int(disp.max()) if len(disp) else 0}")
+    ref_of = torch.full((int(partner.max()) + 1,), -1, dtype=torch.int64)        # device position -> reference index
+    ref_of[partner[ok]] = pos[ok]
+    worst, worst_ulp, pairs = 0.0, 0.0, 0
+    for j in range(len(ref_of)):
+        for k in range(j + 1, min(j + 2 * max_shift + 2, len(ref_of))):
+            a, b = int(ref_of[j]), int(ref_of[k])
+            if a >= 0 and b >= 0 and a > b:                                      # device ranks a before b, the reference b before a
+                gap = abs(float(ref_logit[a]) - float(ref_logit[b]))
+                ulp = 2.0 ** (math.floor(math.log2(max(abs(float(ref_logit[a])), 1e-30))) - 23)
+                pairs += 1
+                worst, worst_ulp = max(worst, gap / (2 * noise)), max(worst_ulp, gap / ulp)
+                assert gap <= 2 * noise, (what, "members swapped although their reference logits differ by more than the implementations' "
+                                          "disagreement", a, b, float(ref_logit[a]), float(ref_logit[b]), noise)
+    print(f"[{what}] order: {moved} of {len(partner)} positions moved, largest displacement {int(disp.max()) if len(disp) else 0}; "
+          f"{pairs} inverted pair(s), worst reference-logit gap = {worst:.3f} x the 2*noise bound (noise {noise:.3g}) = {worst_ulp:.1f} ulp of the logit")
     assert moved <= max_moved and (len(disp) == 0 or int(disp.max()) <= max_shift), (what, moved, int(disp.max()))
+
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -41,9 +62,9 @@ def world():
     img = torch.from_numpy(synth.frames(300, 1, 800, 800)[0])
     with torch.no_grad():
         ofe, osz, opad = OM.extract_features([img], sd)                       # default transform: 800 / 1333
-        oprops, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
+        oprops, oobj, odlt = OM.rpn_proposals(ofe, osz, opad, sd)
         ref, _, _ = OM.video_matchrcnn_forward([img], sd)
-    return dict(m=m, sd=sd, img=img, ofe=ofe, osz=osz, oprops=oprops, ref=ref[0])
+    return dict(m=m, sd=sd, img=img, ofe=ofe, osz=osz, opad=opad, oprops=oprops, oobj=oobj, odlt=odlt, ref=ref[0])
 
 
 def test_rpn_proposals_800(world):
@@ -53,8 +74,23 @@ def test_rpn_proposals_800(world):
         p = m.rpn(feats, sizes, padded)[0].cpu()
     assert tuple(padded) == (800, 800) and len(o) == 1000 and len(p) == 1000            # post-NMS top-n is full at this size
     partner = assert_same_set(o, p, tol_px=1e-2, what="RPN proposals 800x800")
-    # ... and in the same objectness order, near-tie neighbour swaps aside
-    assert_same_order(partner, "RPN proposals 800x800")
+    # ... and in the same objectness order wherever the reference's own logits separate two members
+    _check_proposal_order(m, feats, partner, o, world["ofe"], world["osz"], world["opad"], world["oobj"], world["odlt"], "RPN proposals 800x800")
+
+
+def _check_proposal_order(m, feats, partner, o, ofe, osz, opad, oobj, odlt, what):
+    """The order half of the proposal comparison: device logits vs reference logits (the noise), then every inverted pair."""
+    from oracle import detection as D
+    with torch.no_grad():
+        dev_obj = torch.cat([o_.reshape(-1) for o_, _ in m.rpn.head(list(feats.values()))]).cpu()     # NHWC == the reference's (h, w, anchor) order
+    anchors = D.grid_anchors(opad, [f.shape[-2:] for f in ofe.values()])
+    rprops, _, ridx = D.rpn_filter_proposals(oobj, odlt, anchors, osz, return_index=True)
+    assert torch.equal(rprops[0], o)
+    ref_obj = torch.cat([t.permute(0, 2, 3, 1).reshape(-1) for t in oobj])
+    assert ref_obj.shape == dev_obj.shape
+    noise = float((dev_obj - ref_obj).abs().max())
+    assert noise <= 1e-3 * float(ref_obj.abs().max())                                   # the north_star tolerance on the logits themselves
+    assert_same_order(partner, what, ref_obj[ridx[0]], noise)
 
 
 def _check_detections(out, ref, what):
@@ -149,7 +185,7 @@ def test_drop_in_forward_other_frames(world, seed, h, w, padded_hw):
     img = torch.from_numpy(synth.frames(seed, 1, h, w)[0])
     with torch.no_grad():
         ofe, osz, opad = OM.extract_features([img], sd)
-        oprops, _, _ = OM.rpn_proposals(ofe, osz, opad, sd)
+        oprops, oobj, odlt = OM.rpn_proposals(ofe, osz, opad, sd)
         ref, _, _ = OM.video_matchrcnn_forward([img], sd)
         feats, sizes, orig, padded = m.extract_features([img.to(DEV)])
         p = m.rpn(feats, sizes, padded)[0].cpu()
@@ -158,6 +194,6 @@ def test_drop_in_forward_other_frames(world, seed, h, w, padded_hw):
     o = oprops[0]
     assert len(o) == len(p)
     partner = assert_same_set(o, p, tol_px=1e-2, what=f"RPN proposals {h}x{w} seed {seed}")
-    assert_same_order(partner, f"RPN proposals {h}x{w} seed {seed}")
+    _check_proposal_order(m, feats, partner, o, ofe, osz, opad, oobj, odlt, f"RPN proposals {h}x{w} seed {seed}")
     assert len(ref[0]["scores"]) == len(out["scores"])
     _check_detections(out, ref[0], f"detections {h}x{w} seed {seed}")

@@ -645,6 +645,23 @@ def test_rpn_topk_decode_matches_sort_and_oracle(ops):
         ops.rpn_topk_decode(hd, a, anc.to(d), clip.to(d), 1025, bx, sc, 0)
 
 
+def test_pointwise_unserved_channel_counts_fall_back(ops):
+    """K = 768 (slab count 3 does not divide an XCD's 32 blocks) is not given to seam_conv1x1_sw_f32 (it would have redone
+    tiles; K = 8448 would have hung): the C ABI rejects it, pack_conv prepares no slab for it, conv2d runs the implicit GEMM."""
+    d = dev()
+    from seam_match_rcnn_amd import _native
+    lib = _native.lib()
+    x, wgt, bias = rnd(70, (2, 64, 20, 20)), rnd(71, (768, 64, 1, 1), "w") / 8.0, rnd(72, (768,), "b")
+    pc = ops.pack_conv(wgt.to(d), bias.to(d))
+    assert pc.ws is None and lib.seam_conv1x1_sw_config(800, 64, 0, 768) == 0
+    xd = nhwc(x).to(d)
+    y = torch.empty((2, 20, 20, 768), device=d)
+    rc = lib.seam_conv1x1_sw_f32(xd.data_ptr(), None, wgt.to(d).reshape(768, 64).contiguous().data_ptr(), bias.to(d).data_ptr(), None, y.data_ptr(),
+                                 800, 64, 0, 768, 0, 0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0
+    assert_close(ops.conv2d(xd, pc, relu=True).permute(0, 3, 1, 2), F.relu(F.conv2d(x, wgt, bias)))
+
+
 @pytest.mark.parametrize("shape", [(2, 48, 72, 256, 128), (2, 48, 72, 256, 256), (3, 40, 56, 64, 256), (1, 14, 14, 256, 1024),
                                    (5, 33, 31, 128, 512), (2, 20, 20, 256, 64), (4, 50, 50, 64, 64)])
 def test_pointwise_weights_stationary_kernel(ops, shape):

@@ -187,7 +187,8 @@ CASES = [(8, 256, 96, 88, 256, 1, 0, 1, True),       # main region + right strip
          (16, 128, 100, 100, 128, 1, 0, 1, True),    # the short K loop (16 chunks)
          (48, 512, 25, 25, 512, 1, 0, 0, False),     # 64 chunks, no ReLU
          (40, 256, 77, 91, 64, 1, 2, 0, False),      # one n-tile pair, ReLU-mask epilogue, ragged map
-         (4, 256, 200, 200, 128, 1, 0, 1, True)]     # many tiles per block (persistent walk), two n-tile pairs
+         (4, 256, 200, 200, 128, 1, 0, 1, True),     # many tiles per block (persistent walk), two n-tile pairs
+         (40, 64, 100, 100, 64, 1, 1, 1, True)]      # 8 chunks per tile: the request stage works a whole tile ahead
 for (n, c, h, w, k, pad, res, relu, bn) in CASES:
     x = torch.from_numpy(synth.normal(synth.stream_id(5, "x"), (n, h, w, c))).to(d)
     wt = torch.from_numpy(synth.normal(synth.stream_id(6, "w"), (k, c, 3, 3))).to(d) / math.sqrt(9 * c)
@@ -220,14 +221,14 @@ def _run_pc_child(env_extra):
     r = subprocess.run([sys.executable, "-c", _PC_CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     rows = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("CASE")]
-    assert len(rows) == 8, r.stdout[-2000:]
+    assert len(rows) == 9, r.stdout[-2000:]
     return rows
 
 
 def test_wino24_producer_consumer_kernel():
     """conv3x3_wino24pc (round 5: the NT = 2 block as MFMA-only consumer waves + transform / load producer waves, persistent over
     its XCD's tiles) on layer shapes that exercise every branch of it -- three-region maps, stacked maps, valid convolution, both
-    K-loop lengths, every epilogue mode, many tiles per block: within 2e-5 of the exact implicit GEMM, repeat launches identical,
+    K-loop lengths (8, 16, 32, 64 chunks), every epilogue mode, many tiles per block: within 2e-5 of the exact implicit GEMM, repeat launches identical,
     and BIT-IDENTICAL to conv3x3_wino24<2> (SEAM_W24_PC=0, the round-4 kernel) and to its own one-tile-per-block launch
     (SEAM_W24_PERSIST=0): the three compute the same fma chains."""
     pc = _run_pc_child({})

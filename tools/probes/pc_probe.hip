@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #pragma clang diagnostic ignored "-Wunused-value"
+#include <string>
 #include <vector>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -109,9 +110,10 @@ __global__ __launch_bounds__(512, 2) void probe(const float* __restrict__ in, fl
     if (lane == 0) stamps[gw] = t1 - t0;
 }
 
+static int g_iters = 2000;
 template <int NACC, int ACCA, int OPER, int NR, int NV, int NW, int PRIO, int GAP = 0, int SWAP = 0, int PU = 1>
 void run(const float* in, float* out, unsigned long long* stamps, const char* tag) {
-    const int iters = 2000, piters = iters;
+    const int iters = g_iters, piters = iters;
     hipFuncSetAttribute((const void*)probe<NACC, ACCA, OPER, NR, NV, NW, PRIO, GAP, SWAP, PU>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<NACC, ACCA, OPER, NR, NV, NW, PRIO, GAP, SWAP, PU>), dim3(256), dim3(512), 65536, 0, in, out, stamps, iters);
     hipDeviceSynchronize();
@@ -126,13 +128,31 @@ void run(const float* in, float* out, unsigned long long* stamps, const char* ta
     fflush(stdout);
 }
 
-int main() {
+// usage: pc_probe                 -- the table of partner-wave experiments (profiles/r05_pc_probe.txt)
+//        pc_probe long [zero]     -- ~1 s of bare back-to-back fp32 MFMAs on every SIMD (random or zero operands), for a clock / power
+//                                    trace sampled beside it (tools/probes/mfma_clock_trace.sh)
+int main(int argc, char** argv) {
+    const bool longrun = argc > 1 && std::string(argv[1]) == "long";
+    const bool zero = argc > 2 && std::string(argv[2]) == "zero";
     float *in, *out; unsigned long long* stamps;
     std::vector<float> h(1 << 18);
     srand(1);
-    for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    for (auto& v : h) v = zero ? 0.f : (float)rand() / RAND_MAX - 0.5f;
     hipMalloc(&in, h.size() * 4); hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&stamps, 256 * 8 * 8);
+    if (longrun) {
+        g_iters = 60000;
+        for (int rep = 0; rep < 8; ++rep) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0);
+            run<12, 0, 0, 0, 0, 0, 0, 0, 0, 1>(in, out, stamps, zero ? "bare MFMAs, zero operands" : "bare MFMAs, random operands");
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            // two launches per run(); MFMAs per launch = 256 CUs x 4 waves x iters x 48, 4096 FLOP each
+            printf("   wall %.1f ms for 2 launches -> %.1f TFLOP/s issued\n", ms, 2.0 * 256 * 4 * (double)g_iters * 48 * 4096 / (ms * 1e-3) / 1e12);
+        }
+        return 0;
+    }
     run<12, 0, 1, 12, 36, 6, 0, 0, 0, 1>(in, out, stamps, "baseline");
     run<12, 0, 1, 12, 36, 6, 0, 0, 0, 2>(in, out, stamps, "producer loop unrolled x2");
     run<12, 0, 1, 12, 36, 6, 0, 0, 0, 4>(in, out, stamps, "producer loop unrolled x4");
