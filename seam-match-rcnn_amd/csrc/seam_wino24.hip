@@ -1112,10 +1112,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         PC_BAR();                               // P2
         PC_BAR();                               // P3
         int tile = tile0;
+        auto u_desc = [&](const int tn) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.u + (size_t)tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
+        };
+        __amdgpu_buffer_rsrc_t u_rsrc = u_desc(pc_geo(p, tile0).tn);
         for (int k = 0; k < ntiles; ++k) {
             const PcGeo q = pc_geo(p, tile);
-            const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)((const char*)p.u + (size_t)q.tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
             auto load_b = [&](int slot_, int nu, int chunk) {
                 const int so = chunk * 24576 + (nu >> 2) * 4096;
 #pragma unroll
@@ -1124,12 +1126,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                     SB();
                 }
             };
-#pragma unroll
-            for (int j = 0; j < RING; ++j) {    // in ring order, pinned: the K loop's vmcnt waits count on it
+            auto ring_preload = [&]() {         // the tile's first RING position instances, in ring order, pinned: the K loop's vmcnt
+#pragma unroll                                  // waits count on that order
+                for (int j = 0; j < RING; ++j) {
+                    SB();
+                    load_b(j, j % 6, j / 6);
+                }
                 SB();
-                load_b(j, j % 6, j / 6);
-            }
-            SB();
+            };
+            if (k == 0) ring_preload();         // later tiles: requested in the previous tile's epilogue
 #pragma unroll
             for (int a = 0; a < AD; ++a) aq[a] = read_a(0, a);
             // one chunk: positions 0..5 in order; c = chunk parity (V buffer), t = chunk index; FIRST: the tile's first chunk
@@ -1215,6 +1220,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) sum += acc[nu][m][r];
                     if (sum == 123456.789f) p.y[tid] = sum;
+                }
+                if (nt == NT - 1 && k + 1 < ntiles) {   // the accumulators are dead: the next tile's first weight fragments travel under
+                    u_rsrc = u_desc(pc_geo(p, tile + S).tn);    // the rest of the epilogue
+                    ring_preload();
                 }
                 PC_TR(22 + 4 * nt);
                 PC_BAR();                       // E1 / E3: ex holds this n-tile

@@ -645,6 +645,41 @@ def test_rpn_topk_decode_matches_sort_and_oracle(ops):
         ops.rpn_topk_decode(hd, a, anc.to(d), clip.to(d), 1025, bx, sc, 0)
 
 
+def test_pointwise_kernel_1000_launches_bit_identical(ops):
+    """every shipped epilogue mode of seam_conv1x1_sw_f32 -- none / ReLU / residual + ReLU / FPN top-down merge /
+    two-source reduction -- launched 1000 times on a ragged map: every result bit-identical to the first (the kernel's waves are
+    independent after the slab copy and its epilogue goes through a wave-private LDS transpose with the residual requested a step
+    ahead: a missing wait or a shared LDS region would show as run-to-run differences, as it did in the reverted round-4 variant)."""
+    d = dev()
+    n, h, w, c, k = 3, 41, 53, 128, 256
+    x, res = rnd(190, (n, c, h, w)), rnd(191, (n, k, h, w))
+    top = rnd(192, (n, k, (h + 1) // 2, (w + 1) // 2))
+    wgt = rnd(193, (k, c, 1, 1), "w") / (c ** 0.5)
+    bn = (torch.from_numpy(synth.uniform(synth.stream_id(194, "bw"), (k,), 0.5, 1.5)), rnd(195, (k,), "bb") * 0.1,
+          rnd(196, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(197, "rv"), (k,), 0.5, 1.5)))
+    pc = ops.pack_conv(wgt.to(d), None, tuple(t.to(d) for t in bn))
+    pcb = ops.pack_conv(wgt.to(d), rnd(198, (k,), "b").to(d))
+    c1 = c // 2
+    pcd = ops.pack_conv_dual(wgt[:, :c1].to(d), tuple(t.to(d) for t in bn), wgt[:, c1:].to(d), tuple(t.to(d) for t in bn))
+    xd, rd, td = nhwc(x).to(d), nhwc(res).to(d), nhwc(top).to(d)
+    xa, xb = nhwc(x[:, :c1]).contiguous().to(d), nhwc(x[:, c1:]).contiguous().to(d)
+    cases = [("plain", lambda: ops.conv2d(xd, pc)), ("relu", lambda: ops.conv2d(xd, pc, relu=True)),
+             ("residual", lambda: ops.conv2d(xd, pc, relu=True, residual=rd)), ("topdown", lambda: ops.conv2d_topdown(xd, pcb, td)),
+             ("dual", lambda: ops.conv2d_dual(xa, xb, pcd, 1, relu=True))]
+    saved = ops.SW
+    try:
+        ops.SW = True
+        assert pc.ws is not None and h * w >= ops.SW_MIN_HW
+        for name, run in cases:
+            first = run()
+            bad = torch.zeros((), dtype=torch.int64, device=d)
+            for _ in range(1000):
+                bad += (run() != first).sum()
+            assert int(bad) == 0, (name, int(bad))
+    finally:
+        ops.SW = saved
+
+
 def test_pointwise_unserved_channel_counts_fall_back(ops):
     """K = 768 (slab count 3 does not divide an XCD's 32 blocks) is not given to seam_conv1x1_sw_f32 (it would have redone
     tiles; K = 8448 would have hung): the C ABI rejects it, pack_conv prepares no slab for it, conv2d runs the implicit GEMM."""

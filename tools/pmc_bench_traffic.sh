@@ -24,7 +24,7 @@ for i in range($i):
     for r in csv.DictReader(open(f)):
         if "conv3x3_wino24" in r["Kernel_Name"]:
             mm = re.search(r"conv3x3_wino24<(\d+)>", r["Kernel_Name"])
-            key = f"conv3x3_wino24<{mm.group(1)}>" if mm else "conv3x3_wino24"
+            key = "conv3x3_wino24pc" if "conv3x3_wino24pc" in r["Kernel_Name"] else f"conv3x3_wino24<{mm.group(1)}>" if mm else "conv3x3_wino24"
             a = agg[r["Counter_Name"]][key]
             a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             continue
