@@ -9,7 +9,7 @@ PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "
 i=0
 for c in "${PASSES[@]}"; do
   rm -rf /tmp/pmc_$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --single-stream "$@" > /dev/null 2>/tmp/pmc_$i.err || echo "pass $c failed"
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --single-stream "$@" > /dev/null 2>/tmp/pmc_$i.err || echo "pass $c failed"
   i=$((i+1))
 done
 python3 - <<PY

@@ -153,12 +153,23 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
-    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 1>(in, out, stamps, "baseline");
-    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 2>(in, out, stamps, "producer loop unrolled x2");
-    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 4>(in, out, stamps, "producer loop unrolled x4");
-    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 8>(in, out, stamps, "producer loop unrolled x8");
-    run<12, 0, 1, 12, 0, 0, 0, 0, 0, 8>(in, out, stamps, "reads only, unrolled x8");
-    run<12, 0, 1, 0, 36, 0, 0, 0, 0, 8>(in, out, stamps, "VALU only, unrolled x8");
-    run<12, 0, 1, 0, 0, 6, 0, 0, 0, 8>(in, out, stamps, "writes only, unrolled x8");
+    // MFMA waves (0-3 of a 512-thread block: 12 accumulator tiles, own operand traffic) beside their SIMD partners (waves 4-7)
+    run<12, 0, 1, 0, 0, 0, 0, 0, 0, 1>(in, out, stamps, "idle partners");
+    run<12, 0, 1, 12, 0, 0, 0, 0, 0, 8>(in, out, stamps, "partners: 12 ds_read_b128 + wait per phase");
+    run<12, 0, 1, 0, 0, 6, 0, 0, 0, 8>(in, out, stamps, "partners: 6 ds_write_b128 + wait per phase");
+    run<12, 0, 1, 0, 36, 0, 0, 0, 0, 8>(in, out, stamps, "partners: 36 v_pk_fma_f32 per phase");
+    run<12, 0, 1, 12, 36, 6, 0, 0, 0, 1>(in, out, stamps, "partners: a transform phase (12 rd, 36 pk, 6 wr)");
+    run<12, 0, 1, 24, 72, 12, 0, 0, 0, 1>(in, out, stamps, "partners: twice that work per phase");
+    run<12, 0, 1, 12, 36, 6, 2, 0, 0, 1>(in, out, stamps, "  ... partners at s_setprio 3");
+    run<12, 0, 1, 12, 36, 6, 1, 0, 0, 1>(in, out, stamps, "  ... MFMA waves at s_setprio 3");
+    run<12, 0, 1, 12, 36, 6, 0, 0, 1, 1>(in, out, stamps, "  ... MFMA waves are the younger half");
+    run<4, 0, 1, 12, 36, 6, 0, 0, 0, 1>(in, out, stamps, "  ... 4 accumulator tiles (16-MFMA loop trips)");
+    run<12, 0, 1, 12, 36, 6, 0, 5, 0, 1>(in, out, stamps, "  ... s_nop 7 (32 cycles) behind every MFMA");
+    run<12, 0, 1, 12, 36, 6, 0, 1, 0, 1>(in, out, stamps, "  ... s_nop 15 (64 cycles) behind every MFMA");
+    run<12, 0, 1, 12, 36, 6, 0, 10, 0, 1>(in, out, stamps, "  ... s_branch behind every MFMA");
+    run<12, 0, 1, 12, 36, 6, 0, 13, 0, 1>(in, out, stamps, "  ... s_sleep 2 behind every 8th MFMA");
+    run<12, 0, 1, 12, 36, 6, 0, 9, 0, 1>(in, out, stamps, "  ... 3 x s_nop 15 behind every 8th MFMA");
+    printf("reading: 'producer cyc/phase' = (partner waves' total cycles) / 2000 phases; the partners keep running after the MFMA waves end,\n"
+           "so a total only slightly above the MFMA waves' total means: (almost) nothing was done beside them.\n");
     return 0;
 }

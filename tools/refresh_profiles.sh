@@ -28,4 +28,14 @@ python3 $R/tools/conv_breakdown.py 8 f32 c2 2>/dev/null | grep -v amdgpu.ids > $
 python3 $R/tools/conv_breakdown.py 8 f16 c5 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_breakdown_c5_f16.txt
 python3 $R/bench.py --workload c4 --force-collective --no-roofline --no-cpu-baseline --no-extras > $O/${TAG}_bench_c4_one_rank_rccl.json 2>/dev/null
 python3 $R/tools/full_forward_timing.py > $O/${TAG}_full_forward.txt 2>/dev/null
+# kernel stats of the drop-in model(images) forward (10 frames; first call packs the weights) -- rocprofv3 directly on the script
+rm -rf /tmp/ff_$TAG
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ff_$TAG -o f -- python3 $R/tools/full_forward_timing.py > /dev/null 2>&1
+(cat /tmp/ff_$TAG/f_kernel_stats.csv 2>/dev/null || cat /tmp/ff_$TAG/*/f_kernel_stats.csv) > $O/${TAG}_full_forward_kernel_stats.csv
+# counters of the fp16 config-5 path (the evidence was missing)
+bash $R/tools/pmc_bench_traffic.sh ${TAG}_f16 --workload c5 --dtype f16 > $O/${TAG}_f16_pmc.log 2>&1
+# the probes behind DESIGN section 3: partner-wave experiments and the clock / power trace of bare fp32 MFMAs
+hipcc -O3 --offload-arch=gfx950 $R/tools/probes/pc_probe.hip -o /tmp/pc_probe 2>/dev/null && /tmp/pc_probe > $O/${TAG}_pc_probe.txt 2>&1
+bash $R/tools/probes/mfma_clock_trace.sh $TAG > /dev/null 2>&1
+bash $R/tools/w24pc_ab.sh $TAG > /dev/null 2>&1
 ls -la $O | grep $TAG
