@@ -157,6 +157,9 @@ struct Wino24Args {
     int nsplit, tns, part_q, part_r;
     unsigned m_tns;
     int total_tiles;             // conv3x3_wino24pc: tiles of the launch (the grid is persistent: min(tiles, CUs) blocks)
+    // conv3x3_wino24pc: a region's parameters side by side -- ONE wide scalar load per tile decode instead of a dozen dependent ones
+    // (the kernel re-derives a tile's geometry from its index in several places; every dependent s_load is ~250 cycles of latency)
+    struct Rg { int TX, TY, bx, by, rx0, ry0, rxe, rye; unsigned m_bx, m_TX, m_PW; int pad_[5]; } rg[3];
     unsigned long long* trace;   // SEAM_W24PC_TRACE builds only: s_memtime stamps of one block's waves 0 and 4 (else null)
 };
 
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
 // The arithmetic (transform expressions, accumulation order, epilogue) is that of conv3x3_wino24<2>: results are bit-identical.
 // =====================================================================================================================
 #ifndef SEAM_W24PC_ABL
-#define SEAM_W24PC_ABL 0    // experiments: 1 no in-loop patch loads / stores, 2 no in-loop weight loads, 8 no in-loop transforms, 16 no epilogue arithmetic
+#define SEAM_W24PC_ABL 0    // experiments: 1 no in-loop patch loads / stores (64: no stores only, 128: no requests only), 2 no in-loop weight loads, 8 no in-loop transforms, 16 no epilogue arithmetic
 #endif
 #ifndef SEAM_W24PC_RING
 #define SEAM_W24PC_RING 4
@@ -694,7 +697,8 @@ static_assert((2 * RAWB) % 16 == 0 && PC_LDS <= 160 * 1024, "LDS map");
 
 // wave-uniform geometry of one tile (SGPRs; recomputed from the tile index where it is needed rather than kept alive)
 struct PcGeo {
-    int tn, reg, n_img, n_here, R0, prow0, ty0, tx0, iy0, ix0, TX, PW, NPIX, HS, PR, NENT, nslots;
+    int tn, reg, n_img, n_here, R0, prow0, ty0, tx0, iy0, ix0, TX, PW, NPIX, HS, PR, NENT, nslots, tye, txe;
+    unsigned m_TX, m_PW;
 };
 __device__ __forceinline__ PcGeo pc_geo(const Wino24Args& p, const int tile) {
     PcGeo g;
@@ -703,21 +707,23 @@ __device__ __forceinline__ PcGeo pc_geo(const Wino24Args& p, const int tile) {
     const int tm_img = fdiv(tm, p.per_img, p.m_per_img);
     int rb = tm - tm_img * p.per_img;
     int reg = 0;
-    if (p.nreg > 1 && rb >= p.bx[0] * p.by[0]) {
-        rb -= p.bx[0] * p.by[0];
+    const int c0 = p.rg[0].bx * p.rg[0].by, c1 = p.rg[1].bx * p.rg[1].by;
+    if (p.nreg > 1 && rb >= c0) {
+        rb -= c0;
         reg = 1;
-        if (p.nreg > 2 && rb >= p.bx[1] * p.by[1]) { rb -= p.bx[1] * p.by[1]; reg = 2; }
+        if (p.nreg > 2 && rb >= c1) { rb -= c1; reg = 2; }
     }
     g.reg = reg;
-    const int TX = p.TX[reg], TY = p.TY[reg];
-    const int byi = fdiv(rb, p.bx[reg], p.m_bx[reg]);
-    const int bxi = rb - byi * p.bx[reg];
+    const Wino24Args::Rg R = p.rg[reg];         // one 64-byte scalar load
+    const int TX = R.TX, TY = R.TY;
+    const int byi = fdiv(rb, R.bx, R.m_bx);
+    const int bxi = rb - byi * R.bx;
     g.R0 = tm * TY;
     g.n_img = p.stack ? fdiv(g.R0, p.tiles_y, p.m_tys) : tm_img;
     g.prow0 = p.stack ? 2 * (g.R0 - g.n_img * p.tiles_y) : 0;
     g.n_here = min(p.G, p.N - g.n_img);
-    g.ty0 = p.stack ? 0 : p.ry0[reg] + byi * TY;
-    g.tx0 = p.stack ? 0 : p.rx0[reg] + bxi * TX;
+    g.ty0 = p.stack ? 0 : R.ry0 + byi * TY;
+    g.tx0 = p.stack ? 0 : R.rx0 + bxi * TX;
     g.iy0 = 2 * g.ty0 - p.pad;
     g.ix0 = 4 * g.tx0 - p.pad;
     g.TX = TX;
@@ -729,24 +735,25 @@ __device__ __forceinline__ PcGeo pc_geo(const Wino24Args& p, const int tile) {
     const int NENT0 = g.PR * ((PH + 1) >> 1);
     g.NENT = NENT0 + ((4 - NENT0) & 7);
     g.nslots = TX * TY;
+    g.m_TX = R.m_TX; g.m_PW = R.m_PW; g.tye = R.rye; g.txe = R.rxe;
     return g;
 }
 // tile slot id (0..31) of a block patch -> image-in-group g, tile row / column, first patch row; false for idle slots
 __device__ __forceinline__ bool pc_slot(const Wino24Args& p, const PcGeo& q, int id, int& g, int& ty, int& tx, int& prow) {
-    const int r = fdiv(id, q.TX, p.m_TX[q.reg]);
-    tx = q.tx0 + (id - r * q.TX);
+    const int r = fdiv(id, q.TX, q.m_TX);
+    tx = q.tx0 + (id - __mul24(r, q.TX));
     if (p.stack) {
         const int R = q.R0 + r;
         const int n = fdiv(R, p.tiles_y, p.m_tys);
         g = n - q.n_img;
-        ty = R - n * p.tiles_y;
-        prow = (2 * p.tiles_y + 2) * g + 2 * ty - q.prow0;
+        ty = R - __mul24(n, p.tiles_y);
+        prow = __mul24(2 * p.tiles_y + 2, g) + 2 * ty - q.prow0;
         return id < q.nslots && n < p.N;
     }
     g = 0;
     ty = q.ty0 + r;
     prow = 2 * r;
-    return id < q.nslots && ty < p.rye[q.reg] && tx < p.rxe[q.reg];
+    return id < q.nslots && ty < q.tye && tx < q.txe;
 }
 
 // second half of the epilogue for one n-tile (all 512 threads; consumers take the output columns 0, 1 of a tile, producers 2, 3).
@@ -777,7 +784,8 @@ __device__ __forceinline__ void pc_finish(const Wino24Args& p, const PcGeo& q, c
         (void*)((const char*)(p.res ? p.res : p.y) + (size_t)q.n_img * out_img), 0, (int)(out_img * q.n_here), 0x00020000);
     const int ncol = (q.tn * 2 + nt) * 32 + n4 * 4;
     const f32x4 sc = epi.sc[nt], sh = epi.sh[nt];
-    const unsigned obase = (unsigned)(((g * p.Ho + oy) * p.Wo + ox) * p.K + ncol) * 4u;
+    // (operands below 2^24: the launcher caps an image group's output at 2^31 bytes and K >= 64 -- the full-rate 24-bit multiply)
+    const unsigned obase = (unsigned)(__mul24(__mul24(__mul24(g, p.Ho) + oy, p.Wo) + ox, p.K) + ncol) * 4u;
     unsigned off[2][2];
     f32x4 rv[2][2];
 #pragma unroll
@@ -792,10 +800,10 @@ __device__ __forceinline__ void pc_finish(const Wino24Args& p, const PcGeo& q, c
 #pragma unroll
     for (int bc = 0; bc < 2; ++bc) {
         const int bcol = (consumer ? 0 : 2) + bc;
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
-        const f32x4 q1 = *reinterpret_cast<const f32x4*>(&ex[((1 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
-        const f32x4 q2 = *reinterpret_cast<const f32x4*>(&ex[((2 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
-        const f32x4 q3 = *reinterpret_cast<const f32x4*>(&ex[((3 * 4 + bcol) * 32 + et) * 32 + n4 * 4]);
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(&ex[((0 * 4 + bcol) * 32 + et) * 32 + (n4 ^ (et & 7)) * 4]);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(&ex[((1 * 4 + bcol) * 32 + et) * 32 + (n4 ^ (et & 7)) * 4]);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(&ex[((2 * 4 + bcol) * 32 + et) * 32 + (n4 ^ (et & 7)) * 4]);
+        const f32x4 q3 = *reinterpret_cast<const f32x4*>(&ex[((3 * 4 + bcol) * 32 + et) * 32 + (n4 ^ (et & 7)) * 4]);
         f32x4 yv[2];
         yv[0] = q0 + q1 + q2;
         yv[1] = q1 - q2 - q3;
@@ -851,6 +859,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
 #endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
+#ifdef SEAM_W24PC_TRACE
+    const unsigned long long blk_t0 = __builtin_amdgcn_s_memtime();
+#endif
     if (!consumer) {
         // =================================================== producer ===================================================
         const int ptid = tid - 256;
@@ -866,25 +877,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         LDSQ char* ra[4];                       // read stage: LDS addresses (raw[0]) of the transform's two patch rows at x phases 0..3
         LDSQ char* rb[4];
         LDSQ char* lpn[NP];                     // the next tile's lp, computed together with its goff (same pixel arithmetic)
+        // (this runs in a burst window, i.e. with the consumers idle: ~440 vector instructions, ~4500 cycles per tile -- 3 % of a
+        //  C = 256 tile.  Products have operands below 2^24 -- launcher-checked: 2^31 bytes per image group, C >= 64 -- and use the
+        //  full-rate 24-bit multiply.  An incremental form (one division, then carries) was tried: hipcc spends the same ~37
+        //  instructions per pixel on its selects and exec masks, no gain.)
         auto setup_patch = [&](const PcGeo& q, LDSQ char* (&lp_)[NP]) {
             const int pitch = 2 * p.tiles_y + 2;
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 const int pix = (ptid >> 3) + 32 * r;
-                const int v = fdiv(pix, q.PW, p.m_PW[q.reg]);
-                const int px = pix - v * q.PW;
+                const int v = fdiv(pix, q.PW, q.m_PW);
+                const int px = pix - __mul24(v, q.PW);
                 int g = 0, gy = q.iy0 + v;
                 if (p.stack) {
                     const int vr = q.prow0 + v;
                     g = fdiv(vr, pitch, p.m_pitch);
-                    gy = vr - g * pitch - p.pad;
+                    gy = vr - __mul24(g, pitch) - p.pad;
                 }
                 const int gx = q.ix0 + px;
                 const bool inb = pix < q.NPIX && g < q.n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-                goff[r] = inb ? (unsigned)((((g * p.H + gy) * p.W + gx) * p.C + (ptid & 7) * 4) * 4) : kOob;
+                goff[r] = inb ? (unsigned)((__mul24(__mul24(__mul24(g, p.H) + gy, p.W) + gx, p.C) + (ptid & 7) * 4) * 4) : kOob;
                 const int half = ptid & 1;
                 lp_[r] = (LDSQ char*)smem + PC_RAW +
-                         (pix < q.NPIX ? (half * q.NENT + (v >> 1) * q.PR + ((v & 1) * 4 + (px & 3)) * q.HS + (px >> 2)) * 16 : 2 * ENTMAX * 16);
+                         (pix < q.NPIX ? (__mul24(half, q.NENT) + __mul24(v >> 1, q.PR) + __mul24((v & 1) * 4 + (px & 3), q.HS) + (px >> 2)) * 16
+                                       : 2 * ENTMAX * 16);
             }
         };
         auto setup_read = [&](const PcGeo& q) {
@@ -893,7 +909,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
             const int rwb = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
             int g, ty, tx, prow;
             if (!pc_slot(p, q, lane & 31, g, ty, tx, prow)) pc_slot(p, q, 0, g, ty, tx, prow);     // idle slots read tile 0 (never stored)
-            const int rbase = ((lane >> 5) * q.NENT + (prow >> 1) * q.PR + (tx - q.tx0)) * 16;
+            const int rbase = (__mul24(lane >> 5, q.NENT) + __mul24(prow >> 1, q.PR) + (tx - q.tx0)) * 16;
             const int oa = ((rwa >> 1) * q.PR + (rwa & 1) * 4 * q.HS) * 16, ob = ((rwb >> 1) * q.PR + (rwb & 1) * 4 * q.HS) * 16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {       // column j: x phase (j & 3) at entry (j >> 2)
@@ -1054,8 +1070,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                     __builtin_amdgcn_s_sleep(SEAM_W24PC_PSLEEP);
 #endif
                     if (!(SEAM_W24PC_ABL & 1)) {
-                        store_chunk(rq[((j + 3) >> 2) & 1], (j + 3) & 3, (j + 3) & 1);
-                        if ((j & 3) == 0) load_group(rq[((j + 3) >> 2) & 1]);
+                        if (!(SEAM_W24PC_ABL & 64)) store_chunk(rq[((j + 3) >> 2) & 1], (j + 3) & 3, (j + 3) & 1);     // 64: requests only
+                        if ((j & 3) == 0 && !(SEAM_W24PC_ABL & 128)) load_group(rq[((j + 3) >> 2) & 1]);           // 128: LDS stores only
                     }
                     tr_read(j & 1);
                     PC_TR(2);
@@ -1156,9 +1172,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                         for (int nt = 0; nt < NT; ++nt) {
                             if (first && kk == 0) {
                                 const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i % (AD + 1)][kk], bq[sl][nt][kk], z, 0, 0, 0);
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[sl][nt][kk], aq[i % (AD + 1)][kk], z, 0, 0, 0);
                             } else {
-                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[i % (AD + 1)][kk], bq[sl][nt][kk], acc[i][nt], 0, 0, 0);
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[sl][nt][kk], aq[i % (AD + 1)][kk], acc[i][nt], 0, 0, 0);
                             }
                             SB();
                         }
@@ -1194,22 +1210,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                 PC_TR(21 + 4 * nt);
                 if (!(SEAM_W24PC_ABL & 16)) {
                     const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+                    // The MFMAs ran with the operand roles swapped (rows = channels, columns = tiles; the products and their order are
+                    // the same, so are the results): a lane holds ONE tile (lane & 31) and, in registers 4m..4m+3, the four consecutive
+                    // channels 8m + 4 (lane >> 5) + 0..3 -- the exchange rows [tile][32 channels] take 16-byte stores (16 per n-tile
+                    // instead of 64 4-byte ones).  16-byte channel group g of a row sits at slot g ^ (tile & 7): conflict-free for the
+                    // stores (eight consecutive tiles per LDS phase) and for pc_finish's reads (eight groups of one row).
+                    const int tl = lane & 31;
 #pragma unroll
-                    for (int h = 0; h < 8; ++h) {
-                        auto rd = [&](int nu) -> f32x2 { return f32x2{acc[nu][nt][2 * h], acc[nu][nt][2 * h + 1]}; };
-                        const f32x2 m0 = rd(0), m1 = rd(1), m2 = rd(2), m3 = rd(3), m4 = rd(4), m5 = rd(5);
-                        const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
-                        const f32x2 y0 = pk_add(pk_add(m0, s12), s34);
-                        const f32x2 y1 = pk_fma_s(c2, d34, d12);
-                        const f32x2 y2 = pk_fma_s(c4, s34, s12);
-                        const f32x2 y3 = pk_add(pk_fma_s(c8, d34, d12), m5);
-                        const int r = 2 * h;
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        float* e0 = &ex[((xi * 4 + 0) * 32 + row) * 32 + (lane & 31)];
-                        e0[0] = y0[0];               e0[32] = y0[1];
-                        e0[1024] = y1[0];            e0[1024 + 32] = y1[1];
-                        e0[2048] = y2[0];            e0[2048 + 32] = y2[1];
-                        e0[3072] = y3[0];            e0[3072 + 32] = y3[1];
+                    for (int m = 0; m < 4; ++m) {
+                        f32x2 yy[4][2];
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int h = 2 * m + hh;
+                            auto rd = [&](int nu) -> f32x2 { return f32x2{acc[nu][nt][2 * h], acc[nu][nt][2 * h + 1]}; };
+                            const f32x2 m0 = rd(0), m1 = rd(1), m2 = rd(2), m3 = rd(3), m4 = rd(4), m5 = rd(5);
+                            const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
+                            yy[0][hh] = pk_add(pk_add(m0, s12), s34);
+                            yy[1][hh] = pk_fma_s(c2, d34, d12);
+                            yy[2][hh] = pk_fma_s(c4, s34, s12);
+                            yy[3][hh] = pk_add(pk_fma_s(c8, d34, d12), m5);
+                        }
+                        const int grp = (2 * m + (lane >> 5)) ^ (tl & 7);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            *reinterpret_cast<f32x4*>(&ex[((xi * 4 + b) * 32 + tl) * 32 + grp * 4]) =
+                                __builtin_shufflevector(yy[b][0], yy[b][1], 0, 1, 2, 3);
                     }
                 } else if (nt == 1) {
                     float sum = 0.f;
@@ -1232,6 +1257,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
             }
             tile += S;
         }
+#ifdef SEAM_W24PC_TRACE
+        if (p.trace && tid == 0) {      // per-block span (cycles) and tile count, behind the two traced waves' stamp areas
+            p.trace[8 * 4096 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - blk_t0;
+            p.trace[8 * 4096 + 2 * blockIdx.x + 1] = (unsigned long long)ntiles;
+        }
+#endif
     }
 #undef SB
 }
@@ -1523,12 +1554,18 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
         // persistent grid: one block per CU walks its XCD's tile range (SEAM_W24_PERSIST=0: one tile per block)
         static const int persist = getenv("SEAM_W24_PERSIST") ? atoi(getenv("SEAM_W24_PERSIST")) : 1;
         a.total_tiles = (int)blocks;
+        for (int r = 0; r < 3; ++r) {
+            a.rg[r].TX = a.TX[r]; a.rg[r].TY = a.TY[r]; a.rg[r].bx = a.bx[r]; a.rg[r].by = a.by[r];
+            a.rg[r].rx0 = a.rx0[r]; a.rg[r].ry0 = a.ry0[r]; a.rg[r].rxe = a.rxe[r]; a.rg[r].rye = a.rye[r];
+            a.rg[r].m_bx = a.m_bx[r]; a.rg[r].m_TX = a.m_TX[r]; a.rg[r].m_PW = a.m_PW[r];
+            for (int e = 0; e < 5; ++e) a.rg[r].pad_[e] = 0;
+        }
         const int ncu = cus[dev & 31].load(std::memory_order_relaxed);
         const unsigned grid = (unsigned)(persist && blocks > ncu ? ncu : blocks);
 #ifdef SEAM_W24PC_TRACE
         static unsigned long long* tbuf = nullptr;
-        if (!tbuf) (void)hipMalloc((void**)&tbuf, 8 * 4096 * 8);
-        (void)hipMemset(tbuf, 0, 8 * 4096 * 8);
+        if (!tbuf) (void)hipMalloc((void**)&tbuf, (8 * 4096 + 2 * 1024) * 8);
+        (void)hipMemset(tbuf, 0, (8 * 4096 + 2 * 1024) * 8);
         a.trace = tbuf;
 #endif
         hipLaunchKernelGGL(conv3x3_wino24pc<SEAM_W24PC_RING>, dim3(grid), dim3(512), PC_LDS, (hipStream_t)stream, a);
@@ -1537,8 +1574,21 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
             static int dumped = 0;
             (void)hipDeviceSynchronize();
             if (dumped++ == 3) {
-                static unsigned long long h[8 * 4096];
+                static unsigned long long h[8 * 4096 + 2 * 1024];
                 (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+                {
+                    unsigned long long mn = ~0ull, mx = 0, sum = 0; int nb = 0;
+                    unsigned long long xs[8] = {0}, xn[8] = {0};
+                    for (unsigned b = 0; b < grid && b < 1024; ++b) {
+                        const unsigned long long v = h[8 * 4096 + 2 * b];
+                        if (!v) continue;
+                        mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; ++nb; xs[b & 7] += v; xn[b & 7]++;
+                    }
+                    fprintf(stderr, "BLOCKSPAN blocks %d min %llu avg %llu max %llu cycles; per XCD avg:", nb, mn, nb ? sum / nb : 0, mx);
+                    for (int x = 0; x < 8; ++x) fprintf(stderr, " %llu", xn[x] ? xs[x] / xn[x] : 0);
+                    fprintf(stderr, "\n");
+                    for (unsigned b = 0; b < grid && b < 1024; b += 37) fprintf(stderr, "BLOCK %u span %llu tiles %llu\n", b, h[8 * 4096 + 2 * b], h[8 * 4096 + 2 * b + 1]);
+                }
                 for (int w = 0; w < 8; w += 4) {
                     unsigned long long prev = 0;
                     for (int k = 0; k < 4096 && h[w * 4096 + k]; ++k) {

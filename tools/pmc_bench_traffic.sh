@@ -33,6 +33,11 @@ for i in range($i):
             a = agg[r["Counter_Name"]][f"conv1x1_sw<{ms.group(1)},{ms.group(2)}>"]
             a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             continue
+        mg = re.search(r"conv_igemmIDF16_Li(\d+)ELi(\d+)ELi(\d+)", r["Kernel_Name"])     # rocprofv3 leaves _Float16 instantiations mangled
+        if mg:
+            a = agg[r["Counter_Name"]][f"conv_igemm<_Float16,{mg.group(1)},{mg.group(2)}>"]
+            a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            continue
         m = pat.search(r["Kernel_Name"])
         if not m:
             continue

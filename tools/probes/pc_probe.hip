@@ -12,7 +12,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NACC, int ACCA, int OPER, int NR, int NV, int NW, int PRIO, int GAP = 0, int SWAP = 0, int PU = 1>
+template <int NACC, int ACCA, int OPER, int NR, int NV, int NW, int PRIO, int GAP = 0, int SWAP = 0, int PU = 1, int NL = 0>
 __global__ __launch_bounds__(512, 2) void probe(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ stamps,
                                                int iters) {
     extern __shared__ char lds[];
@@ -89,6 +89,12 @@ __global__ __launch_bounds__(512, 2) void probe(const float* __restrict__ in, fl
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) x[i] = *reinterpret_cast<const f32x4*>(lds + 8192 + (wid - 4) * 1024 + lane * 16 + (i & 3) * 16 * 0 + (i >> 2) * 4096 * 0);
+            if (NL) {                               // NL global requests per phase (1 KiB each, a 24 MiB window per CU walked line by line)
+                const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, 1 << 20, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < NL; ++i)
+                    x[i % 12] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, ((it * NL + i) & 1023) * 1024, 0));
+            }
             if (NR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -111,11 +117,11 @@ __global__ __launch_bounds__(512, 2) void probe(const float* __restrict__ in, fl
 }
 
 static int g_iters = 2000;
-template <int NACC, int ACCA, int OPER, int NR, int NV, int NW, int PRIO, int GAP = 0, int SWAP = 0, int PU = 1>
+template <int NACC, int ACCA, int OPER, int NR, int NV, int NW, int PRIO, int GAP = 0, int SWAP = 0, int PU = 1, int NL = 0>
 void run(const float* in, float* out, unsigned long long* stamps, const char* tag) {
     const int iters = g_iters, piters = iters;
-    hipFuncSetAttribute((const void*)probe<NACC, ACCA, OPER, NR, NV, NW, PRIO, GAP, SWAP, PU>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<NACC, ACCA, OPER, NR, NV, NW, PRIO, GAP, SWAP, PU>), dim3(256), dim3(512), 65536, 0, in, out, stamps, iters);
+    hipFuncSetAttribute((const void*)probe<NACC, ACCA, OPER, NR, NV, NW, PRIO, GAP, SWAP, PU, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<NACC, ACCA, OPER, NR, NV, NW, PRIO, GAP, SWAP, PU, NL>), dim3(256), dim3(512), 65536, 0, in, out, stamps, iters);
     hipDeviceSynchronize();
     std::vector<unsigned long long> st(256 * 8);
     hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost);
@@ -123,8 +129,8 @@ void run(const float* in, float* out, unsigned long long* stamps, const char* ta
     for (int b = 0; b < 256; ++b)
         for (int w = 0; w < 8; ++w) (w < 4 ? cm : cp) += (double)st[b * 8 + w];
     cm /= 1024; cp /= 1024;
-    printf("gap=%d swap=%d pu=%d %-44s NACC=%2d acc=%s oper=%d | producer %2d rd %2d pk %d wr prio=%d | cyc/MFMA %6.1f | producer cyc/phase %7.1f  (MFMA waves ran %.0f, producers %.0f cycles)\n",
-           GAP, SWAP, PU, tag, NACC, ACCA ? "AGPR" : "VGPR", OPER, NR, NV, NW, PRIO, cm / (iters * NACC * 4.0), cp / piters, cm, cp);
+    printf("gap=%d swap=%d pu=%d nl=%d %-44s NACC=%2d acc=%s oper=%d | producer %2d rd %2d pk %d wr prio=%d | cyc/MFMA %6.1f | producer cyc/phase %7.1f  (MFMA waves ran %.0f, producers %.0f cycles)\n",
+           GAP, SWAP, PU, NL, tag, NACC, ACCA ? "AGPR" : "VGPR", OPER, NR, NV, NW, PRIO, cm / (iters * NACC * 4.0), cp / piters, cm, cp);
     fflush(stdout);
 }
 
@@ -169,6 +175,11 @@ int main(int argc, char** argv) {
     run<12, 0, 1, 12, 36, 6, 0, 10, 0, 1>(in, out, stamps, "  ... s_branch behind every MFMA");
     run<12, 0, 1, 12, 36, 6, 0, 13, 0, 1>(in, out, stamps, "  ... s_sleep 2 behind every 8th MFMA");
     run<12, 0, 1, 12, 36, 6, 0, 9, 0, 1>(in, out, stamps, "  ... 3 x s_nop 15 behind every 8th MFMA");
+    // vector-memory requests of the partners: do they slow the MFMA waves (which issue two requests per eight MFMAs themselves)?
+    run<12, 0, 1, 0, 0, 0, 0, 0, 0, 8, 3>(in, out, stamps, "partners: 3 global requests per phase, nothing else");
+    run<12, 0, 1, 0, 0, 0, 0, 0, 0, 8, 12>(in, out, stamps, "partners: 12 global requests per phase, nothing else");
+    run<12, 0, 0, 0, 0, 0, 0, 0, 0, 8, 12>(in, out, stamps, "partners: 12 requests per phase; MFMA waves without operand traffic");
+    run<12, 0, 1, 12, 0, 6, 0, 0, 0, 8, 12>(in, out, stamps, "partners: 12 requests + 12 LDS reads + 6 LDS writes per phase");
     printf("reading: 'producer cyc/phase' = (partner waves' total cycles) / 2000 phases; the partners keep running after the MFMA waves end,\n"
            "so a total only slightly above the MFMA waves' total means: (almost) nothing was done beside them.\n");
     return 0;
