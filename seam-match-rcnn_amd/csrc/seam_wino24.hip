@@ -877,11 +877,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         LDSQ char* ra[4];                       // read stage: LDS addresses (raw[0]) of the transform's two patch rows at x phases 0..3
         LDSQ char* rb[4];
         LDSQ char* lpn[NP];                     // the next tile's lp, computed together with its goff (same pixel arithmetic)
-        // (this runs in a burst window, i.e. with the consumers idle: ~440 vector instructions, ~4500 cycles per tile -- 3 % of a
-        //  C = 256 tile.  Products have operands below 2^24 -- launcher-checked: 2^31 bytes per image group, C >= 64 -- and use the
-        //  full-rate 24-bit multiply.  An incremental form (one division, then carries) was tried: hipcc spends the same ~37
-        //  instructions per pixel on its selects and exec masks, no gain.)
+        // (this runs in a burst window, i.e. with the consumers idle: ~440 vector instructions = 3100 cycles in its general form --
+        //  2.5 % of a C = 256 tile, measured with stamps.  Products have operands below 2^24 -- launcher-checked: 2^31 bytes per
+        //  image group, C >= 64 -- and use the full-rate 24-bit multiply.  Consecutive tiles of a block mostly lie in the same
+        //  region of a non-stacked map: their patch has the same shape, so each piece's patch coordinates (kept packed in `vp`)
+        //  and LDS address are unchanged and only the image offset and the border tests are redone -- ~150 instructions.)
+        int vp[NP];                             // piece r's patch row | column << 16 in the region `vp_reg` (row 0x7fff: no pixel)
+        int vp_reg = -1;                        // -1: nothing cached (stacked maps: the image wrap differs from tile to tile)
         auto setup_patch = [&](const PcGeo& q, LDSQ char* (&lp_)[NP]) {
+            if (!p.stack && q.reg == vp_reg) {
+#pragma unroll
+                for (int r = 0; r < NP; ++r) {
+                    const int v = vp[r] & 0xffff, px = vp[r] >> 16;
+                    const int gy = q.iy0 + v, gx = q.ix0 + px;
+                    const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;      // v = 0x7fff fails the row test
+                    goff[r] = inb ? (unsigned)((__mul24(__mul24(gy, p.W) + gx, p.C) + (ptid & 7) * 4) * 4) : kOob;
+                }
+                return;                         // lp_ (= lpn): this region's addresses already
+            }
             const int pitch = 2 * p.tiles_y + 2;
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
@@ -901,7 +914,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                 lp_[r] = (LDSQ char*)smem + PC_RAW +
                          (pix < q.NPIX ? (__mul24(half, q.NENT) + __mul24(v >> 1, q.PR) + __mul24((v & 1) * 4 + (px & 3), q.HS) + (px >> 2)) * 16
                                        : 2 * ENTMAX * 16);
+                vp[r] = pix < q.NPIX ? (v | (px << 16)) : 0x7fff;
             }
+            vp_reg = p.stack ? -1 : q.reg;
         };
         auto setup_read = [&](const PcGeo& q) {
             // input transform of row xi: T_j = d[ra][j] + cb * d[rb][j]  (rows: xi0: d0 - d2, xi1: d1 + d2, xi2: d2 - d1, xi3: d1 - d3)
@@ -933,6 +948,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         {
             const PcGeo q0 = pc_geo(p, tile0);
             setup_patch(q0, lp);
+#pragma unroll
+            for (int r = 0; r < NP; ++r) lpn[r] = lp[r];        // the fast path above leaves lpn alone
             setup_read(q0);
             rsrcL = x_desc(q0);
         }
