@@ -303,6 +303,8 @@ def evaluate_tables(t: DescriptorTables, temporal_aggregator, k_thresholds: Sequ
                 ti += 1
                 if iou > best_iou:
                     best, best_iou = k, iou
+            if not tracks:      # the reference fails here too (np.stack of an empty list, evaluate_movingfashion.py:211): say why
+                raise ValueError(f"evaluate: product {p} has no street detections (the model's empty-image fallback box normally prevents this)")
             members = np.asarray(tracks[best])
             chosen.append(members[np.argsort(t.street_imgs[dets][members], kind="stable")])    # frames in unique_imgs order (:225)
 
@@ -407,6 +409,8 @@ def evaluate_tables_per_product(t: DescriptorTables, temporal_aggregator, k_thre
             iou = float(ops.box_iou(boxes[torch.as_tensor(members, device=dev)], gt).cpu().numpy().max(-1).sum())
             if iou > best_iou:
                 best, best_iou = ti, iou
+        if not tracks:          # the reference fails here too (np.stack of an empty list, evaluate_movingfashion.py:211): say why
+            raise ValueError("evaluate: a product has no street detections (the model's empty-image fallback box normally prevents this)")
         members = np.asarray(tracks[best])
         rep.track_lens.append(len(members))
         members = members[np.argsort(imgs[members], kind="stable")]          # frames visited in unique_imgs order (:225)

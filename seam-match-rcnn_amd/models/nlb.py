@@ -17,6 +17,20 @@ from torch import nn
 from .. import ops
 
 
+class _ForwardOnly(torch.autograd.Function):
+    """Identity on a forward-kernel result that makes it a differentiable-looking output: backward() raises."""
+
+    @staticmethod
+    def forward(ctx, z, t, *deps):
+        ctx.t = int(t)
+        return z.clone()
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError(f"NONLocalBlock1D: the grad-enabled pass supports sequences of <= 64 frames, got {ctx.t} "
+                                  "(seam_nlb_block_bwd_f32 keeps a sequence in LDS); the forward result is valid")
+
+
 class _NonLocalBlockND(nn.Module):
     def __init__(self, in_channels, inter_channels=None, dimension=3, sub_sample=True, bn_layer=True):
         super().__init__()
@@ -74,13 +88,16 @@ class _NonLocalBlockND(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             # grad-enabled direct call: the same forward kernel with the block's own backward behind it (t <= 64)
             if x.shape[-1] > 64:
-                # fail here, not later inside backward() (seam_nlb_block_bwd_f32 keeps a sequence in LDS: hipErrorInvalidValue);
-                # inference on longer sequences: call under torch.no_grad()
-                raise NotImplementedError(f"NONLocalBlock1D: grad-enabled pass supports sequences of <= 64 frames, got {x.shape[-1]}; "
-                                          "wrap inference calls in torch.no_grad()")
+                # The backward kernel keeps a sequence in LDS (<= 64 frames).  The reference module accepts such a call, and an
+                # eval-mode call without torch.no_grad() is one (parameters require grad by default): run the forward kernel and
+                # hand out a result whose BACKWARD raises, with a clear message, if anyone asks for it.
+                return _ForwardOnly.apply(self._forward_nograd(x), x.shape[-1], x, *self.parameters())
             from ..autograd import NlbBlockFunction
             return NlbBlockFunction.apply(x, self.theta.weight, self.theta.bias, self.phi.weight, self.phi.bias, self.g.weight,
                                           self.g.bias, self.concat_project[0].weight, self.W.weight, self.W.bias)
+        return self._forward_nograd(x)
+
+    def _forward_nograd(self, x):
         b, c, t = x.shape
         xt = ops.nchw_to_nhwc(x.detach().contiguous().view(b, c, t))            # [b,t,256]
         lens = torch.full((b,), t, dtype=torch.int32, device=x.device)

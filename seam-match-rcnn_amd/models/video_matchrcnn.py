@@ -242,7 +242,11 @@ class TemporalRoIHeads(nn.Module):
 
 class VideoMatchRCNN(nn.Module):
     roi_heads_cls = TemporalRoIHeads
-    ONE_SYNC = True
+    # True: padded RPN proposals, ONE host synchronisation per forward (the box head then runs on N x post_nms_top_n padded rows);
+    # False: the reference's list form (one more sync, the box head on the real proposal count); None (default): True when
+    # rpn_post_nms_top_n_test <= 1000 -- the video model -- and False beyond (MatchRCNN's 4000: the padded rows would multiply the
+    # box head's work when NMS keeps far fewer).  An instance may set its own `model.ONE_SYNC`.
+    ONE_SYNC = None
 
     def __init__(self, backbone, num_classes, n_frames=3, min_size=800, max_size=1333,
                  rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_test=1000, rpn_nms_thresh=0.7,
@@ -291,7 +295,8 @@ class VideoMatchRCNN(nn.Module):
         feats, sizes, orig, padded = self.extract_features([i.detach() for i in images])
         # padded proposals: the forward synchronises with the device ONCE, at the detection counts (ONE_SYNC = False: the
         # reference's list form, one more sync at the RPN's variable-length split; identical results, tested)
-        proposals = self.rpn(feats, sizes, padded, padded_out=self.ONE_SYNC)
+        one_sync = self.ONE_SYNC if self.ONE_SYNC is not None else self.rpn.post_nms_top_n <= 1000
+        proposals = self.rpn(feats, sizes, padded, padded_out=bool(one_sync))
         if targets is not None:        # GT boxes arrive in original-image pixels -> resized frame
             targets = [dict(t, boxes=det.GeneralizedRCNNTransform.rescale_boxes(
                 t["boxes"].to(feats["0"].device).to(torch.float32), o, s)) for t, s, o in zip(targets, sizes, orig)]

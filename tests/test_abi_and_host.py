@@ -195,12 +195,19 @@ def test_state_dict_keys_and_both_torchvision_layouts():
         m.train()([torch.zeros(3, 32, 32)])
 
 
-def test_grad_enabled_nlb_rejects_long_sequences_up_front():
-    """A grad-enabled direct call of the non-local block on more than 64 frames fails in forward() with a clear message (the
-    backward kernel keeps a sequence in LDS and would only fail inside backward())."""
+def test_grad_enabled_nlb_long_sequences_fail_in_backward_only():
+    """A grad-enabled direct call of the non-local block on more than 64 frames returns the forward kernel's result (the reference
+    module accepts such calls; an eval-mode call without no_grad is one) and raises, with a clear message, only if backward() is
+    asked for (the backward kernel keeps a sequence in LDS).  Without a GPU the forward itself fails loudly -- no CPU fallback."""
     import pytest
     import torch
-    from seam_match_rcnn_amd.models.nlb import NONLocalBlock1D
+    from seam_match_rcnn_amd import _native
+    from seam_match_rcnn_amd.models.nlb import NONLocalBlock1D, _ForwardOnly
     blk = NONLocalBlock1D(256, sub_sample=False, bn_layer=False)
-    with pytest.raises(NotImplementedError, match="<= 64 frames"):
+    with pytest.raises(_native.SeamNativeError):
         blk(torch.zeros(1, 256, 65, requires_grad=True))
+    z = torch.zeros(1, 256, 65)
+    out = _ForwardOnly.apply(z, 65, torch.zeros(3, requires_grad=True))
+    assert out.requires_grad and torch.equal(out, z)
+    with pytest.raises(NotImplementedError, match="<= 64 frames"):
+        out.sum().backward()

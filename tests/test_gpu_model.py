@@ -350,7 +350,7 @@ def test_one_sync_forward_equals_list_form(model_and_state):
             m.roi_heads.score_thresh = thr
             outs = []
             for one in (True, False):
-                type(m).ONE_SYNC = one
+                m.ONE_SYNC = one
                 with torch.no_grad():
                     outs.append(m(imgs))
             for a, b in zip(*outs):
@@ -358,7 +358,7 @@ def test_one_sync_forward_equals_list_form(model_and_state):
                 for k in a:
                     assert torch.equal(a[k], b[k]), k
     finally:
-        type(m).ONE_SYNC = True
+        del m.ONE_SYNC                # back to the class default (by post-NMS proposal count)
         m.roi_heads.score_thresh = old
 
 
