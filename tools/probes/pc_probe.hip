@@ -48,7 +48,10 @@ __global__ __launch_bounds__(512, 2) void probe(const float* __restrict__ in, fl
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        if (ACCA) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[2 * g + nt]) : "v"(a[kk]), "v"(b[nt][kk]));
+                        if (ACCA == 2) {        // fp16 MFMA (32x32x16, fp32 accumulate): the matrix core proper, not the fp32 FMA lanes
+                            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                            acc[2 * g + nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b[nt]), acc[2 * g + nt], 0, 0, 0);
+                        } else if (ACCA) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[2 * g + nt]) : "v"(a[kk]), "v"(b[nt][kk]));
                         else acc[2 * g + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[nt][kk], acc[2 * g + nt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         // GAP: what the MFMA wave does while its MFMA executes (the partner wave needs issue slots)
@@ -130,7 +133,7 @@ void run(const float* in, float* out, unsigned long long* stamps, const char* ta
         for (int w = 0; w < 8; ++w) (w < 4 ? cm : cp) += (double)st[b * 8 + w];
     cm /= 1024; cp /= 1024;
     printf("gap=%d swap=%d pu=%d nl=%d %-44s NACC=%2d acc=%s oper=%d | producer %2d rd %2d pk %d wr prio=%d | cyc/MFMA %6.1f | producer cyc/phase %7.1f  (MFMA waves ran %.0f, producers %.0f cycles)\n",
-           GAP, SWAP, PU, NL, tag, NACC, ACCA ? "AGPR" : "VGPR", OPER, NR, NV, NW, PRIO, cm / (iters * NACC * 4.0), cp / piters, cm, cp);
+           GAP, SWAP, PU, NL, tag, NACC, ACCA == 2 ? "f16 " : ACCA ? "AGPR" : "VGPR", OPER, NR, NV, NW, PRIO, cm / (iters * NACC * 4.0), cp / piters, cm, cp);
     fflush(stdout);
 }
 
@@ -175,6 +178,11 @@ int main(int argc, char** argv) {
     run<12, 0, 1, 12, 36, 6, 0, 10, 0, 1>(in, out, stamps, "  ... s_branch behind every MFMA");
     run<12, 0, 1, 12, 36, 6, 0, 13, 0, 1>(in, out, stamps, "  ... s_sleep 2 behind every 8th MFMA");
     run<12, 0, 1, 12, 36, 6, 0, 9, 0, 1>(in, out, stamps, "  ... 3 x s_nop 15 behind every 8th MFMA");
+    // the same partners beside fp16 MFMAs (v_mfma_f32_32x32x16_f16): is their vector ALU free there?
+    run<12, 2, 1, 0, 0, 0, 0, 0, 0, 1>(in, out, stamps, "fp16 MFMA waves, idle partners");
+    run<12, 2, 1, 0, 36, 0, 0, 0, 0, 8>(in, out, stamps, "fp16 MFMA waves; partners: 36 v_pk_fma_f32 per phase");
+    run<12, 2, 1, 12, 36, 6, 0, 0, 0, 1>(in, out, stamps, "fp16 MFMA waves; partners: a transform phase");
+    run<12, 2, 1, 24, 72, 12, 0, 0, 0, 1>(in, out, stamps, "fp16 MFMA waves; partners: twice that");
     // vector-memory requests of the partners: do they slow the MFMA waves (which issue two requests per eight MFMAs themselves)?
     run<12, 0, 1, 0, 0, 0, 0, 0, 0, 8, 3>(in, out, stamps, "partners: 3 global requests per phase, nothing else");
     run<12, 0, 1, 0, 0, 0, 0, 0, 0, 8, 12>(in, out, stamps, "partners: 12 global requests per phase, nothing else");
