@@ -437,6 +437,25 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
                             seam_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * 3x3 / stride-1 convolution, fp16 operands / fp32 accumulation, producer / consumer form (csrc/seam_f16pc.hip, round 5): the
+ * config-5 path's 3x3 layers (ResNet / FPN / RPN / mask head / match trunk; ref models/video_matchrcnn.py:337-338,
+ * models/match_head.py:50-58) with the input patch staged in LDS once per 64-channel chunk instead of gathered nine times.  Same
+ * contract as seam_conv2d_f16 on those shapes (NHWC fp16 in / out, per-channel fp32 scale / shift, ReLU) except that a residual
+ * operand is NOT taken (`residual` must be NULL, else hipErrorInvalidValue: no 3x3 layer of the path has one, and the kernel's
+ * epilogue rounds to fp16 in the accumulator registers); fp32 accumulation in a different order than seam_conv2d_f16 (chunk-major
+ * instead of tap-major): results agree to fp32 rounding of the accumulation, not bit for bit.  Weights:
+ * seam_f16pc_weight_halves(K, Cstore) fp16 values from seam_pack_conv_weight_f16pc (OIHW fp32 in; MFMA fragment order).  Shapes:
+ * seam_conv3x3_f16pc_supported (C a multiple of 128, K a multiple of 128, pad 0 | 1; maps of >= 24 output columns or whole maps
+ * of <= 16 x 16 outputs); seam_conv3x3_f16pc_pays = supported AND expected faster than seam_conv2d_f16 (tiles >= 3/4 full; a
+ * function of the map geometry only, not of N) -- the rule the host side dispatches by. */
+int seam_conv3x3_f16pc_supported(int N, int H, int W, int C, int K, int pad);
+int seam_conv3x3_f16pc_pays(int N, int H, int W, int C, int K, int pad);
+long long seam_f16pc_weight_halves(int K, int Cstore);
+int seam_pack_conv_weight_f16pc(const float* w, void* w_packed, int K, int Cin, int Cstore, seam_stream_t stream);
+int seam_conv3x3_f16pc(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
+                       int N, int H, int W, int C, int K, int pad, int relu, seam_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * The match trunk as one call (SURVEY.md 8b `seam_match_trunk_f32`): MatchPredictor / TemporalAggregationNLB's
  * conv_seq (4 valid 3x3 convs + ReLU, 14 -> 12 -> 10 -> 8 -> 6) -> AvgPool2d(6,6) + ReLU -> Linear(1024,256) + BatchNorm1d
  * (ref models/match_head.py:50-62,67-69,93-95).  roi NHWC [K,14,14,256] -> x3 [K,256].  Six launches on `stream` (why the

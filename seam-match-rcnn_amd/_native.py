@@ -63,6 +63,11 @@ SIGNATURES = {
     "seam_pack_conv_weight_wino24_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "seam_conv3x3_wino24_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv3x3_wino_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv3x3_f16pc_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "seam_conv3x3_f16pc_pays": (_i, [_i, _i, _i, _i, _i, _i]),
+    "seam_f16pc_weight_halves": (C.c_longlong, [_i, _i]),
+    "seam_pack_conv_weight_f16pc": (_i, [_p, _p, _i, _i, _i, _p]),
+    "seam_conv3x3_f16pc": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv_kred_f16": (_i, [_i, _i, _i]),
     "seam_pack_conv_weight_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

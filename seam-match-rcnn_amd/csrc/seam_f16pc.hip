@@ -15,13 +15,20 @@
 //     one tap straight out of the patch (address = the lane's pixel + an immediate tap offset: the nine taps re-read LDS, not
 //     memory); per eight MFMAs one 1-KiB global load takes the wave's own B fragment (weights packed in fragment order) through
 //     a register ring.  One barrier per chunk (288 MFMAs per wave = 9216 cycles).
-//   * epilogue: accumulators (pixels in lanes, four consecutive channels per register quad: the MFMA's operand roles are swapped)
-//     -> fp32 exchange rows [pixel][128 channels] in LDS, 64 pixels per pass -> all 512 threads: scale / shift (+ residual),
-//     ReLU, fp16, 16-byte NHWC stores.
+//   * epilogue: the consumers finish their own accumulators in registers (pixels in lanes, four consecutive channels per register
+//     quad -- the MFMA's operand roles are swapped; the tile's scale / shift vectors come from a 1-KiB LDS row the producers
+//     filled during the last chunk): fp32 scale / shift, fp16 rounding, ReLU, then 8-byte swizzled writes of the whole
+//     256 x 128 fp16 tile into LDS -- over the patch buffer the tile's LAST chunk just left, which nobody needs before the next
+//     tile's chunk 1 -- ONE barrier, and on to the next tile's first chunk (its first B fragments were requested before the
+//     finishing arithmetic).  The producers drain the tile to memory (16-byte NHWC stores) beside that chunk's MFMAs.
+//     (The first form went through fp32 exchange rows in four passes of two barriers, all 512 threads finishing: 7.9 k of a
+//     tile's 50 k cycles, profiles/r05_f16pc_trace.txt.)  A residual operand is not taken: no 3x3 layer of the path has one.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
+#include <stdio.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,23 +45,31 @@ constexpr int PXB = 144;                    // LDS bytes per patch pixel: 128 (6
 constexpr int NPIXMAX = 352;                // patch pixels per buffer (8 x 32 outputs: 10 x 34 = 340)
 constexpr int PBUF = NPIXMAX * PXB;         // 50688
 constexpr int NP = NPIXMAX * 8 / 256;       // 16-byte pieces per producer thread and chunk: 11
-constexpr int EXROW = 512 + 16;             // exchange row: 128 fp32 channels + 16 (33 slots: odd)
-constexpr int EXPIX = 64;                   // pixels per epilogue pass
-constexpr int EX = 2 * PBUF;                // LDS map: patch[2] | exchange
-constexpr int LDS_BYTES = EX + EXPIX * EXROW;
+constexpr int EX = PBUF;                    // LDS map: patch[2]; the finished fp16 tile (256 pixels x 256 bytes) overlays patch 1 and beyond;
+constexpr int SS = EX + 65536;              // then the tile's scale[128] | shift[128] fp32 row
+constexpr int DC = SS + 1024;               // then the producers' drain count
+constexpr int LDS_BYTES = DC + 16;
+static_assert(2 * PBUF <= SS, "the finished tile must cover patch buffer 1");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
 constexpr int RB = 12;                      // B fragments in flight per consumer wave (36 steps per chunk: the ring's phase repeats every chunk)
 
+#ifndef SEAM_F16PC_ABL
+#define SEAM_F16PC_ABL 0     // experiments: 1 no in-loop A fragment reads, 2 no in-loop B fragment loads, 4 no patch staging
+#endif
 #define LDSQ __attribute__((address_space(3)))
 #define F16_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef SEAM_F16PC_TRACE
+#define F16_TR(tag) do { if (tr_on) { const unsigned long long tm_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && tr_k < 2048) p.trace[wave * 2048 + tr_k] = tm_ | ((unsigned long long)(tag) << 56); ++tr_k; } } while (0)
+#else
+#define F16_TR(tag) do { } while (0)
+#endif
 
 struct F16Args {
     const void* x;         // [N, H, W, C] fp16
     const void* w;         // packed: [K/128][4 n-tiles][C/64 chunks][9 taps][4 k-steps][64 lanes][8 fp16]
     const float* scale;    // [K] or null
     const float* shift;    // [K] or null
-    const void* res;       // [N, Ho, Wo, K] fp16 or null
     void* y;               // [N, Ho, Wo, K] fp16
     int N, H, W, C, K, pad, relu;
     int Ho, Wo;
@@ -66,17 +81,19 @@ struct F16Args {
     int tiles_m, tiles_n, nchunks, total_tiles;
     unsigned m_tiles_n, m_bx, m_per_img, m_PWi, m_HoWo, m_Wo, m_slotpix;
     int per_img;           // mode 0: bx * by
+    unsigned long long* trace;   // SEAM_F16PC_TRACE builds only
 };
 
 __device__ __forceinline__ int fdivu(int a, int d, unsigned m) { return d == 1 ? a : (int)__umulhi((unsigned)a, m); }
 
 // wave-uniform geometry of one tile
 struct F16Geo { int tn, img0, n_here, y0, x0; };
+template <int MODE>
 __device__ __forceinline__ F16Geo f16_geo(const F16Args& p, const int tile) {
     F16Geo g;
     const int tm = fdivu(tile, p.tiles_n, p.m_tiles_n);
     g.tn = tile - tm * p.tiles_n;
-    if (p.mode == 0) {
+    if (MODE == 0) {
         const int img = fdivu(tm, p.per_img, p.m_per_img);
         const int rb = tm - img * p.per_img;
         const int byi = fdivu(rb, p.bx, p.m_bx);
@@ -89,8 +106,9 @@ __device__ __forceinline__ F16Geo f16_geo(const F16Args& p, const int tile) {
     return g;
 }
 // output slot o (0..255) of a block -> image slot, output row / column inside the patch
+template <int MODE>
 __device__ __forceinline__ void f16_slot(const F16Args& p, const int o, int& g, int& oy, int& ox) {
-    if (p.mode == 0) { g = 0; oy = o >> 5; ox = o & 31; return; }
+    if (MODE == 0) { g = 0; oy = o >> 5; ox = o & 31; return; }
     const int HoWo = p.Ho * p.Wo;
     g = fdivu(o, HoWo, p.m_HoWo);
     const int rm = o - g * HoWo;
@@ -106,6 +124,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < 4;
+    constexpr int MODE = PWI == 34 ? 0 : 1;          // large maps in 8 x 32 patches | G whole small maps per block
     const int n = p.nchunks;
 
     // ---- the block's tiles: XCD x (= blockIdx & 7) owns a contiguous range of the launch's tiles; its blocks walk it interleaved ----
@@ -120,46 +139,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
     const int tile0 = start + sl0;
     const size_t img_bytes = (size_t)p.H * p.W * p.C * 2;
     const size_t out_img = (size_t)p.Ho * p.Wo * p.K * 2;
-    float* const ex = reinterpret_cast<float*>(smem + EX);
-
-    // second half of the epilogue for one pass (64 output slots x 128 channels): every thread finishes two 8-channel pieces
-    auto finish = [&](const F16Geo& q, const int pass) {
-        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((char*)p.y + (size_t)q.img0 * out_img), 0, (int)(out_img * q.n_here), 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((const char*)(p.res ? p.res : p.y) + (size_t)q.img0 * out_img), 0, (int)(out_img * q.n_here), 0x00020000);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int piece = tid + 512 * it;              // 0..1023: slot-in-pass = piece >> 4, 8-channel group = piece & 15
-            const int sp = piece >> 4, cg = piece & 15;
-            const int o = pass * EXPIX + sp;
-            int g, oy, ox;
-            f16_slot(p, o, g, oy, ox);
-            const int gy = q.y0 + oy, gx = q.x0 + ox;
-            const bool ok = g < q.n_here && gy < p.Ho && gx < p.Wo && (p.mode == 0 || o < p.G * p.Ho * p.Wo);
-            const int ncol = q.tn * 128 + cg * 8;
-            const unsigned off = ok ? (unsigned)(__mul24(__mul24(__mul24(g, p.Ho) + gy, p.Wo) + gx, p.K) + ncol) * 2u : kOob;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ex) + sp * EXROW + cg * 32);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ex) + sp * EXROW + cg * 32 + 16);
-            f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
-            if (p.scale) { s0 = *reinterpret_cast<const f32x4*>(p.scale + ncol); s1 = *reinterpret_cast<const f32x4*>(p.scale + ncol + 4); }
-            if (p.shift) { h0 = *reinterpret_cast<const f32x4*>(p.shift + ncol); h1 = *reinterpret_cast<const f32x4*>(p.shift + ncol + 4); }
-            f32x4 a0 = v0 * s0 + h0, a1 = v1 * s1 + h1;
-            if (p.res) {
-                const f16x8 rv = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a0[e] += (float)rv[e]; a1[e] += (float)rv[e + 4]; }
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a0[e] = fmaxf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f); }
-            }
-            f16x8 hv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { hv[e] = (_Float16)a0[e]; hv[e + 4] = (_Float16)a1[e]; }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, off, 0, 0);
-        }
-    };
+#ifdef SEAM_F16PC_TRACE
+    const bool tr_on = p.trace && blockIdx.x == SEAM_F16PC_TRACE && (wave & 3) == 0;
+    int tr_k = 0;
+#endif
 
     if (!consumer) {
         // =================================================== producer ===================================================
@@ -171,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 const int pix = (ptid >> 3) + 32 * r;
-                const int g = p.mode ? fdivu(pix, slotpix, p.m_slotpix) : 0;
+                const int g = MODE ? fdivu(pix, slotpix, p.m_slotpix) : 0;
                 const int rm = pix - g * slotpix;
                 const int iy = fdivu(rm, p.PWi, p.m_PWi);
                 const int ix = rm - iy * p.PWi;
@@ -201,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
         // request stage gets there).
         int tile = tile0, ck = 0;               // the tile / chunk the REQUEST stage is at
         int tiles_left = ntiles;
-        F16Geo q = f16_geo(p, tile);
+        F16Geo q = f16_geo<MODE>(p, tile);
         setup(q);
         __amdgpu_buffer_rsrc_t rs = x_desc(q);
         auto request = [&](f32x4 (&dst)[NP]) {
@@ -210,12 +193,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
                 ck = 0;
                 tile += S;
                 if (--tiles_left > 0) {
-                    q = f16_geo(p, tile);
+                    q = f16_geo<MODE>(p, tile);
                     setup(q);
                     rs = x_desc(q);
                 }
             }
         };
+        if (ptid == 0) *reinterpret_cast<LDSQ unsigned*>((LDSQ char*)smem + DC) = 0u;
         request(rq[0]);                         // chunk 0
         request(rq[1]);                         // chunk 1
         store_chunk(rq[0], 0);
@@ -225,23 +209,79 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
         int c = 0;
         for (int k = 0; k < ntiles; ++k) {
             for (int t = 0; t < n; t += 2) {    // two chunks per trip: the register sets' parity is a compile-time constant
+                if (t == n - 2 && ptid < 64) {  // the tile's epilogue vectors -> LDS (read by the consumers after the last chunk's barrier)
+                    const int i4 = (ptid & 31) * 4;
+                    const float* src = ptid < 32 ? p.scale : p.shift;
+                    const float dflt = ptid < 32 ? 1.f : 0.f;
+                    const int tl = tile0 + k * S;
+                    const int tn = tl - fdivu(tl, p.tiles_n, p.m_tiles_n) * p.tiles_n;
+                    const f32x4 vv = src ? *reinterpret_cast<const f32x4*>(src + tn * 128 + i4) : f32x4{dflt, dflt, dflt, dflt};
+                    *reinterpret_cast<f32x4 LDSQ*>((LDSQ char*)smem + SS + ptid * 16) = vv;
+                }
                 // chunk c (even position in the tile): chunk c + 1 registers (set 1) -> buffer 1; request chunk c + 3 into set 1
+                F16_TR(11);
+#if !(SEAM_F16PC_ABL & 4)
                 if (c + 1 < total_chunks) store_chunk(rq[1], 1);
                 request(rq[1]);
+#endif
+                F16_TR(12);
                 F16_BAR();
                 ++c;
+#if !(SEAM_F16PC_ABL & 4)
                 if (c + 1 < total_chunks) store_chunk(rq[0], 0);
                 request(rq[0]);
+#endif
                 F16_BAR();
                 ++c;
             }
-            // the tile's epilogue: four passes, two barriers each (exchange written / exchange free)
-            const F16Geo qe = f16_geo(p, tile0 + k * S);
-#pragma unroll 1
-            for (int pass = 0; pass < 256 / EXPIX; ++pass) {
-                F16_BAR();
-                finish(qe, pass);
-                F16_BAR();
+            // the tile's epilogue: the consumers' finished fp16 tile -> memory, beside the next tile's first chunk
+            F16_BAR();                          // E: the tile is in LDS
+            {
+                int tl = tile0 + k * S;
+                asm volatile("" : "+s"(tl));    // the 16 store offsets are computed HERE, not hoisted above the tile's chunk loop (they spilled there)
+                const F16Geo qe = f16_geo<MODE>(p, tl);
+                const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)((char*)p.y + (size_t)qe.img0 * out_img), 0, (int)(out_img * qe.n_here), 0x00020000);
+                const int piece = ptid & 15;
+                const int ncol = qe.tn * 128 + piece * 8;
+                int ob = ptid >> 4;
+                asm volatile("" : "+v"(ob));    // (as above: the rows' output coordinates are launch invariants the compiler would keep live for the whole kernel)
+#pragma unroll
+                for (int hf = 0; hf < 4; ++hf) {
+                    u32x4 v[4];
+                    SB();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int o = (hf * 4 + i) * 16 + ob;
+                        v[i] = *reinterpret_cast<const u32x4 LDSQ*>((LDSQ char*)smem + EX + o * 256 + ((piece ^ (o & 15)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int it = hf * 4 + i;
+                        const int o = it * 16 + ob;
+                        int g, oy, ox;
+                        f16_slot<MODE>(p, o, g, oy, ox);
+                        const int gy = qe.y0 + oy, gx = qe.x0 + ox;
+                        const bool ok = g < qe.n_here && gy < p.Ho && gx < p.Wo && (MODE == 0 || o < p.G * p.Ho * p.Wo);
+                        const unsigned off = ok ? (unsigned)(__mul24(__mul24(__mul24(g, p.Ho) + gy, p.Wo) + gx, p.K) + ncol) * 2u : kOob;
+                        // rows with bit 4 set keep their two 8-byte halves swapped (the consumers' conflict-free write pattern)
+                        const u32x4 w = (it & 1) ? u32x4{v[i][2], v[i][3], v[i][0], v[i][1]} : v[i];
+                        __builtin_amdgcn_raw_buffer_store_b128(w, y_rsrc, off, 0, 0);
+                    }
+                    SB();
+                }
+            }
+            // D: every producer wave is through with the tile's rows before any of them puts the next tile's chunk 1 over them (the
+            // four waves drain interleaved rows and store interleaved patch pixels; without D a fast wave's patch stores ran into
+            // a slow wave's rows: a handful of wrong pixels per launch).  A count in LDS among the four producer waves -- the
+            // consumers are in the middle of their chunk 0 and take no part.  (LDS operations of a wave execute in order: a
+            // wave's increment follows its row reads.)
+            if (k + 1 < ntiles) {
+                LDSQ unsigned* const cnt = reinterpret_cast<LDSQ unsigned*>((LDSQ char*)smem + DC);
+                if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned want = 4u * (unsigned)(k + 1);
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
             }
         }
     } else {
@@ -253,8 +293,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             int g, oy, ox;
-            f16_slot(p, 32 * m + (lane & 31), g, oy, ox);
-            if (p.mode && 32 * m + (lane & 31) >= p.G * p.Ho * p.Wo) { g = 0; oy = 0; ox = 0; }      // idle slots read pixel 0 (never stored)
+            f16_slot<MODE>(p, 32 * m + (lane & 31), g, oy, ox);
+            if (MODE && 32 * m + (lane & 31) >= p.G * p.Ho * p.Wo) { g = 0; oy = 0; ox = 0; }      // idle slots read pixel 0 (never stored)
             ab[m] = (LDSQ char*)smem + (__mul24(g, p.PHi * PWI) + oy * PWI + ox) * PXB + (lane >> 5) * 16;
         }
         const int wchunk_bytes = 9 * 4 * 1024;                      // one chunk of one n-tile: 9 taps x 4 k-steps x 1 KiB
@@ -264,20 +304,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
         f32x4 bf[RB];                           // B fragments: step s in slot s % RB
         int tile = tile0;
         F16_BAR();                              // P
-        for (int k = 0; k < ntiles; ++k) {
-            const F16Geo q = f16_geo(p, tile);
-            const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)((const char*)p.w + (size_t)(q.tn * 4 + wn) * wtile_bytes), 0, wtile_bytes, 0x00020000);
-            auto load_b = [&](const int slot, const int step) {     // step = global step of the tile: chunk * 36 + tap * 4 + ks
-                bf[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, blane, step * 1024, 0));
-            };
+        __amdgpu_buffer_rsrc_t w_rsrc;
+        auto load_b = [&](const int slot, const int step) {         // step = global step of the tile: chunk * 36 + tap * 4 + ks
+            bf[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, blane, step * 1024, 0));
+        };
+        auto ring_preload = [&](const int tl) {                     // the first RB fragments of tile tl's own weight slice
+            const F16Geo q = f16_geo<MODE>(p, tl);
+            w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w + (size_t)(q.tn * 4 + wn) * wtile_bytes), 0, wtile_bytes, 0x00020000);
 #pragma unroll
             for (int s = 0; s < RB; ++s) { SB(); load_b(s, s); }
             SB();
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        };
+        ring_preload(tile);
+        for (int k = 0; k < ntiles; ++k) {
+            F16_TR(1);
             for (int t = 0; t < n; ++t) {
                 // this chunk's patch buffer: the lanes' pixel addresses move by one buffer (8 adds per 288 MFMAs)
                 LDSQ char* ac[8];
@@ -294,32 +334,69 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
                     for (int m = 0; m < 8; ++m) {
                         SB();
                         // roles swapped: rows = output channels (the B fragment), columns = pixels (the A fragment)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[st % RB]), __builtin_bit_cast(f16x8, af[m]), acc[m], 0, 0, 0);
+                        if (st == 0 && t == 0) {     // the tile's first step multiplies into a constant zero: no accumulator clears
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[st % RB]), __builtin_bit_cast(f16x8, af[m]), z, 0, 0, 0);
+                        } else {
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[st % RB]), __builtin_bit_cast(f16x8, af[m]), acc[m], 0, 0, 0);
+                        }
                         SB();
+#if !(SEAM_F16PC_ABL & 1)
                         if (st + 1 < 36) af[m] = read_a(m, st + 1);      // the same pixel group's fragment of the next step
+#endif
                     }
                     SB();
+#if !(SEAM_F16PC_ABL & 2)
                     load_b(st % RB, t * 36 + st + RB);                  // past the tile's end: zero fill, never used
+#endif
                 }
                 SB();
+                F16_TR(2);
                 F16_BAR();                      // chunk t + 1 is in the other buffer; this one may be overwritten
+                F16_TR(3);
             }
-            // ---- epilogue: four passes of 64 output slots (pixel groups 2 pass, 2 pass + 1) through the fp32 exchange rows ----
-#pragma unroll
-            for (int pass = 0; pass < 256 / EXPIX; ++pass) {
-#pragma unroll
-                for (int mm = 0; mm < 2; ++mm) {
-                    const int m = 2 * pass + mm;
-                    char* row = reinterpret_cast<char*>(ex) + (32 * mm + (lane & 31)) * EXROW + wn * 128 + (lane >> 5) * 16;
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd)      // registers 4 qd .. 4 qd + 3 = channels 8 qd + 4 (lane >> 5) + 0..3 of this wave's 32
-                        *reinterpret_cast<f32x4*>(row + qd * 32) = f32x4{acc[m][4 * qd], acc[m][4 * qd + 1], acc[m][4 * qd + 2], acc[m][4 * qd + 3]};
-                }
-                F16_BAR();
-                finish(q, pass);
-                F16_BAR();
-            }
+            // ---- epilogue ----
             tile += S;
+            F16_TR(4);
+            if (k + 1 < ntiles) ring_preload(tile);     // in flight under the finishing arithmetic
+            f32x4 sc[4], sh[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {    // this lane's 16 channels: 8 qd + 4 (lane >> 5) + 0..3 of the wave's 32
+                sc[qd] = *reinterpret_cast<const f32x4 LDSQ*>((LDSQ char*)smem + SS + (wn * 32 + 8 * qd + 4 * (lane >> 5)) * 4);
+                sh[qd] = *reinterpret_cast<const f32x4 LDSQ*>((LDSQ char*)smem + SS + 512 + (wn * 32 + 8 * qd + 4 * (lane >> 5)) * 4);
+            }
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            int le = lane;
+            asm volatile("" : "+v"(le));        // the 40 row / piece addresses below are computed here, not kept (spilled) across the chunk loop
+            auto finish_tile = [&](auto relu_c) {        // ReLU as a compile-time constant: two copies of the loop, no per-value selects
+                constexpr bool RELU = decltype(relu_c)::value;
+                const f16x2 lo = f16x2{(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int o = 32 * m + (le & 31);
+                    // row o: 16 pieces of 16 bytes, piece index XOR (o & 15); rows with bit 4 set swap the 8-byte halves of a piece
+                    LDSQ char* row = (LDSQ char*)smem + EX + o * 256 + ((((le >> 5) ^ (o >> 4)) & 1) << 3);
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const f32x2 a0 = f32x2{acc[m][4 * qd], acc[m][4 * qd + 1]} * f32x2{sc[qd][0], sc[qd][1]} + f32x2{sh[qd][0], sh[qd][1]};
+                        const f32x2 a1 = f32x2{acc[m][4 * qd + 2], acc[m][4 * qd + 3]} * f32x2{sc[qd][2], sc[qd][3]} + f32x2{sh[qd][2], sh[qd][3]};
+                        f16x2 h0 = __builtin_convertvector(a0, f16x2), h1 = __builtin_convertvector(a1, f16x2);
+                        if (RELU) {             // after the rounding: the same values as ReLU before it (monotone, 0 exact)
+                            h0 = __builtin_elementwise_max(h0, lo);
+                            h1 = __builtin_elementwise_max(h1, lo);
+                        }
+                        u32x2 pk;
+                        pk[0] = __builtin_bit_cast(unsigned, h0);
+                        pk[1] = __builtin_bit_cast(unsigned, h1);
+                        *reinterpret_cast<u32x2 LDSQ*>(row + (((wn * 4 + qd) ^ (o & 15)) << 4)) = pk;
+                    }
+                }
+            };
+            if (p.relu) finish_tile(std::true_type{}); else finish_tile(std::false_type{});
+            F16_TR(5);
+            F16_BAR();                          // E: the producers take it from here
+            F16_TR(6);
         }
     }
 }
@@ -403,8 +480,33 @@ int f16pc_launch(const F16Args& a, hipStream_t st) {
     }
     const int ncu = cus[dev & 31].load(std::memory_order_relaxed);
     const unsigned grid = (unsigned)(a.total_tiles > ncu ? ncu : a.total_tiles);
+#ifdef SEAM_F16PC_TRACE
+    static unsigned long long* tbuf = nullptr;
+    if (!tbuf) (void)hipMalloc((void**)&tbuf, 8 * 2048 * 8);
+    (void)hipMemset(tbuf, 0, 8 * 2048 * 8);
+    F16Args b = a; b.trace = tbuf;
+    hipLaunchKernelGGL(conv3x3_f16pc<PWI>, dim3(grid), dim3(512), LDS_BYTES, st, b);
+    {
+        static int dumped = 0;
+        (void)hipDeviceSynchronize();
+        if (dumped++ == 2) {
+            static unsigned long long h[8 * 2048];
+            (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+            for (int w = 0; w < 8; w += 4) {
+                unsigned long long prev = 0;
+                for (int k = 0; k < 2048 && h[w * 2048 + k]; ++k) {
+                    const unsigned long long v = h[w * 2048 + k], tm = v & 0x00ffffffffffffffull;
+                    fprintf(stderr, "TR wave %d k %d tag %d d %lld\n", w, k, (int)(v >> 56), prev ? (long long)(tm - prev) : 0ll);
+                    prev = tm;
+                }
+            }
+        }
+    }
+    return (int)hipGetLastError();
+#else
     hipLaunchKernelGGL(conv3x3_f16pc<PWI>, dim3(grid), dim3(512), LDS_BYTES, st, a);
     return (int)hipGetLastError();
+#endif
 }
 
 }  // namespace
@@ -416,6 +518,17 @@ extern "C" {
 int seam_conv3x3_f16pc_supported(int N, int H, int W, int C, int K, int pad) {
     F16Args a;
     return f16pc_plan(a, N, H, W, C, K, pad) == 0 ? 1 : 0;
+}
+
+/* 1 when the kernel is also expected to beat conv_igemm<_Float16,256,128> on this map geometry: its 256-slot tiles must be >= 3/4
+ * full (measured, profiles/r05_f16pc_ab.txt: 1.47x at 95 % fill, 1.23-1.38x at 77-88 %, 1.03x at 75 %, 0.87-0.95x at 56-70 %).
+ * The batch size takes no part: a frame gives the same bits alone as inside a batch (tests/test_gpu_config5.py). */
+int seam_conv3x3_f16pc_pays(int N, int H, int W, int C, int K, int pad) {
+    F16Args a;
+    if (f16pc_plan(a, N, H, W, C, K, pad)) return 0;
+    const double slots = a.mode == 0 ? (double)a.bx * a.by * 256.0 : 256.0;
+    const double used = a.mode == 0 ? (double)a.Ho * a.Wo : (double)a.G * a.Ho * a.Wo;
+    return used >= 0.75 * slots ? 1 : 0;
 }
 
 long long seam_f16pc_weight_halves(int K, int Cstore) { return (long long)K * Cstore * 9; }
@@ -432,8 +545,9 @@ int seam_pack_conv_weight_f16pc(const float* w, void* w_packed, int K, int Cin, 
 int seam_conv3x3_f16pc(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
                        int N, int H, int W, int C, int K, int pad, int relu, void* stream) {
     F16Args a;
-    if (f16pc_plan(a, N, H, W, C, K, pad)) return (int)hipErrorInvalidValue;
-    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.res = residual; a.y = y; a.relu = relu;
+    if (residual || f16pc_plan(a, N, H, W, C, K, pad)) return (int)hipErrorInvalidValue;
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y; a.relu = relu;
+    a.trace = nullptr;
     hipStream_t st = (hipStream_t)stream;
     switch (a.PWi) {
         case 34: return f16pc_launch<34>(a, st);

@@ -62,6 +62,7 @@ class PackedConv:
     wn: Optional[torch.Tensor] = None   # fp32 1x1 layers with <= 16 outputs: register-resident weights of seam_linear_narrow_f32
     ws: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C <= 256: row-major [K, C] weights (scale folded) of seam_conv1x1_sw_f32
     shift_sw: Optional[torch.Tensor] = None   # ... and its shift vector (zeros when the layer has none)
+    wh: Optional[torch.Tensor] = None   # fp16 stride-1 3x3 layers (C, K multiples of 128): fragment-order weights of seam_conv3x3_f16pc
 
 
 BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
@@ -71,6 +72,10 @@ BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per pr
 # arithmetic; SEAM_WINOGRAD=0 keeps every layer on the implicit-GEMM kernel.
 import os as _os
 WINOGRAD = _os.environ.get("SEAM_WINOGRAD", "1") != "0"
+# fp16 path: the stride-1 3x3 layers with C, K multiples of 128 through the producer / consumer kernel (csrc/seam_f16pc.hip);
+# SEAM_F16PC=0 keeps them on the implicit GEMM
+F16PC = _os.environ.get("SEAM_F16PC", "1") != "0"
+F16PC_RULE = True      # dispatch by seam_conv3x3_f16pc_pays (False: every supported shape -- tests, tools/f16pc_ab.py)
 
 
 def _pack_wino(lib, weight: torch.Tensor, K: int, cin: int, cs: int, mode: int) -> Optional[torch.Tensor]:
@@ -177,7 +182,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
     epv = 8 if dtype == F16 else 4
     cs = cstore if cstore is not None else ((cin + epv - 1) // epv) * epv
     rows = lib.seam_conv_rows_padded(K)
-    u = u24 = None
+    u = u24 = wh = None
     if dtype == F32:
         kred = lib.seam_conv_kred(cs, R, S)
         wp = torch.empty((rows, kred), dtype=F32, device=weight.device)
@@ -197,6 +202,9 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         wp = torch.empty((rows, kred), dtype=F16, device=weight.device)
         _native.check(lib.seam_pack_conv_weight_f16(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
                       "seam_pack_conv_weight_f16")
+        if F16PC and mode == 0 and R == 3 and S == 3 and stride == 1 and pad in (0, 1) and cs % 128 == 0 and K % 128 == 0:
+            wh = torch.empty((int(lib.seam_f16pc_weight_halves(K, cs)),), dtype=F16, device=weight.device)
+            _native.check(lib.seam_pack_conv_weight_f16pc(_ptr(weight), _ptr(wh), K, cin, cs, _stream()), "seam_pack_conv_weight_f16pc")
     scale = shift = None
     if bias is not None:
         bias = bias.detach().to(F32)
@@ -224,7 +232,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         wm = (weight.permute(2, 3, 1, 0).reshape(K, cin) if transposed2x2 else weight.reshape(K, cin)).to(F32)
         ws = (wm * scale[:, None] if scale is not None else wm).contiguous()
         shift_sw = shift if shift is not None else torch.zeros((K,), dtype=F32, device=weight.device)
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw)
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw, wh)
 
 
 def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -> PackedConv:
@@ -408,6 +416,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     wino = pc.dtype == F32 and pc.u is not None and WINOGRAD and out_hw is None and _wino_pays(lib, n, h, w, c, pc.K, pc.pad)
     wino24 = wino and pc.u24 is not None and WINOGRAD24 and _wino24_pays(lib, n, h, w, c, pc.K, pc.pad)
     sw = not narrow and pc.dtype == F32 and out_hw is None and _sw_ok(pc, h, w)
+    f16pc = (pc.dtype == F16 and pc.wh is not None and F16PC and residual is None and out_hw is None and not out_f32 and relu in (0, 1, False, True)
+             and (lib.seam_conv3x3_f16pc_pays if F16PC_RULE else lib.seam_conv3x3_f16pc_supported)(n, h, w, c, pc.K, pc.pad) == 1)
     if narrow:
         _native.check(lib.seam_linear_narrow_f32(_ptr(x), _ptr(pc.wn), _ptr(pc.shift), _ptr(y), n * h * w, c, pc.K, int(relu), _stream()),
                       "seam_linear_narrow_f32")
@@ -430,6 +440,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
         _native.check(lib.seam_conv2d_bx3(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                           n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, int(relu), _stream()),
                       "seam_conv2d_bx3")
+    elif f16pc:
+        _native.check(lib.seam_conv3x3_f16pc(_ptr(x), _ptr(pc.wh), _ptr(pc.scale), _ptr(pc.shift), None, _ptr(y),
+                                             n, h, w, c, pc.K, pc.pad, 1 if relu else 0, _stream()), "seam_conv3x3_f16pc")
     else:
         _native.check(lib.seam_conv2d_f16(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                           n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, 1 if relu else 0,
@@ -446,6 +459,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
                        else f"conv3x3_wino24<{lib.seam_wino24_variant(n, h, w, c, pc.K, pc.pad)}>")
         elif wino:
             variant = f"conv3x3_wino<{lib.seam_wino_tile_variant(n, h, w, c, pc.K, pc.pad)}>"
+        elif f16pc:
+            variant = "conv3x3_f16pc"
         elif pc.dtype == BX3:
             variant = f"conv_igemm_bx3<{tile // 1000},{tile % 1000}>"
         else:

@@ -154,3 +154,123 @@ def test_vector_epilogue_f16_tails_and_residual(ops):
         y = ops.conv2d(nhwc(x).half().to(d), pc, True, None if resid is None else nhwc(resid).half().to(d))
         assert y.dtype == H
         assert_close(y.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
+
+
+def _f16pc_case(ops, seed, n, c, hh, ww, k, pad, relu, bn):
+    d = dev()
+    x = rnd(seed, (n, c, hh, ww)).half().float()
+    wt = (rnd(seed + 1, (k, c, 3, 3), "w") / (3 * math.sqrt(c)))
+    if bn:
+        b = (torch.from_numpy(synth.uniform(synth.stream_id(seed + 2, "bw"), (k,), 0.5, 1.5)), rnd(seed + 3, (k,), "bb") * 0.1,
+             rnd(seed + 4, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(seed + 5, "rv"), (k,), 0.5, 1.5)))
+        pc = ops.pack_conv(wt.to(d), None, stride=1, pad=pad, bn=tuple(t.to(d) for t in b), dtype=H)
+    else:
+        b = rnd(seed + 2, (k,), "b") * 0.1
+        pc = ops.pack_conv(wt.to(d), b.to(d), stride=1, pad=pad, dtype=H)
+    return x, wt, b, pc
+
+
+def _f16pc_ref(x, wt, b, pc, pad, relu, bn):
+    """fp32 convolution of the fp16-rounded operands the pack stores (scale / shift stay fp32 in the epilogue)."""
+    if bn:
+        sc = b[0] * (b[3] + 1e-5).rsqrt()
+        folded = pc.scale is None                      # the pack either folds the BN scale into the weights or keeps it in the epilogue
+        w16 = ((wt * sc[:, None, None, None]) if folded else wt).half().float()
+        ref = F.conv2d(x, w16, None, 1, pad)
+        ref = (ref if folded else ref * sc[None, :, None, None]) + (b[1] - b[2] * sc)[None, :, None, None]
+    else:
+        ref = F.conv2d(x, wt.half().float(), b, 1, pad)
+    return F.relu(ref) if relu else ref
+
+
+@pytest.mark.parametrize("case", [
+    # n, C, H, W, K, pad, relu, bn            mode 0: 8 x 32 output patches, ragged right / bottom edges, both paddings
+    (3, 128, 27, 45, 128, 1, True, True), (2, 256, 40, 70, 256, 0, False, False), (1, 128, 9, 26, 256, 1, True, False),
+    # mode 1: whole small maps, G per block, a partial last block (n % G != 0), every supported patch width
+    (37, 256, 14, 14, 256, 1, True, False), (23, 256, 8, 8, 1024, 0, True, False), (9, 256, 12, 12, 256, 0, False, True),
+    (11, 128, 10, 10, 128, 0, True, False), (5, 128, 14, 14, 128, 0, True, False), (4, 256, 16, 16, 128, 0, True, True),
+    (7, 128, 6, 6, 128, 1, True, False),
+])
+def test_conv3x3_f16pc_matches_fp32_on_fp16_operands(ops, case):
+    """seam_conv3x3_f16pc (producer / consumer fp16 3x3) against the fp32 convolution of the same fp16-rounded operands -- the bound of
+    the implicit-GEMM tests above -- and against conv_igemm<_Float16> to accumulation-order rounding."""
+    import seam_match_rcnn_amd._native as native
+    n, c, hh, ww, k, pad, relu, bn = case
+    assert native.lib().seam_conv3x3_f16pc_supported(n, hh, ww, c, k, pad) == 1
+    x, wt, b, pc = _f16pc_case(ops, 900, n, c, hh, ww, k, pad, relu, bn)
+    assert pc.wh is not None
+    ref = _f16pc_ref(x, wt, b, pc, pad, relu, bn)
+    xd = nhwc(x).half().to(dev())
+    old = ops.F16PC, ops.F16PC_RULE, ops.CONV_TRACE
+    try:
+        ops.F16PC_RULE = False
+        ops.F16PC = True
+        ops.CONV_TRACE = []
+        got = ops.conv2d(xd, pc, relu)
+        assert [t[0] for t in ops.CONV_TRACE] == ["conv3x3_f16pc"]
+        ops.CONV_TRACE = None
+        ops.F16PC = False
+        ig = ops.conv2d(xd, pc, relu)
+    finally:
+        ops.F16PC, ops.F16PC_RULE, ops.CONV_TRACE = old
+    assert got.dtype == H and got.shape == ig.shape
+    assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
+    scale = float(ref.abs().max())
+    assert float((got.float() - ig.float()).abs().max()) <= 2e-3 * scale        # two fp16 roundings of nearly equal fp32 sums
+
+
+def test_conv3x3_f16pc_many_tiles_per_block_is_repeatable(ops):
+    """The persistent walk (several tiles per block: the cross-tile patch pipeline, the finished tile laid over the free patch buffer and
+    drained by the producer waves beside the next tile's first chunk): five launches bit-identical, equal to the implicit GEMM to
+    rounding on EVERY image, no output left unwritten.  (The drain once raced the next tile's patch stores: a few wrong pixels in
+    one launch of three, on exactly these shapes.)"""
+    d = dev()
+    old = ops.F16PC, ops.F16PC_RULE
+    try:
+        ops.F16PC_RULE = False
+        for seed, (n, c, hh, ww, k, pad) in enumerate([(1536, 256, 12, 12, 256, 0), (1536, 256, 8, 8, 1024, 0), (24, 256, 96, 168, 256, 1)]):
+            g = torch.Generator(device=d); g.manual_seed(40 + seed)
+            x = torch.randn(n, hh, ww, c, device=d, generator=g).half()
+            wt = torch.randn(k, c, 3, 3, device=d, generator=g) / (3 * math.sqrt(c))
+            bias = torch.randn(k, device=d, generator=g) * 0.1
+            pc = ops.pack_conv(wt, bias, stride=1, pad=pad, dtype=H)
+            ops.F16PC = False
+            ig = ops.conv2d(x, pc, True)
+            ops.F16PC = True
+            first = None
+            for rep in range(5):
+                y = torch.full_like(ig, 777.0)
+                ops.conv2d(x, pc, True, out=y)
+                assert int((y == 777.0).sum()) == 0
+                if first is None:
+                    first = y
+                    scale = float(ig.float().abs().max())
+                    assert float((y.float() - ig.float()).abs().max()) <= 2e-3 * scale
+                else:
+                    assert torch.equal(y, first), f"launch {rep} differs"
+    finally:
+        ops.F16PC, ops.F16PC_RULE = old
+
+
+def test_conv3x3_f16pc_refuses_a_residual_and_dispatch_rule(ops):
+    import seam_match_rcnn_amd._native as native
+    lib = native.lib()
+    d = dev()
+    x = torch.zeros(2, 16, 16, 128, dtype=H, device=d)
+    pc = ops.pack_conv(torch.zeros(128, 128, 3, 3, device=d), torch.zeros(128, device=d), stride=1, pad=1, dtype=H)
+    y = torch.zeros(2, 16, 16, 128, dtype=H, device=d)
+    rc = lib.seam_conv3x3_f16pc(x.data_ptr(), pc.wh.data_ptr(), None, pc.shift.data_ptr(), y.data_ptr(), y.data_ptr(), 2, 16, 16, 128, 128, 1, 1, None)
+    assert rc != 0
+    # a residual layer stays on the implicit GEMM
+    ops.CONV_TRACE = []
+    try:
+        ops.conv2d(x, pc, True, y.clone())
+        assert ops.CONV_TRACE[0][0].startswith("conv_igemm")
+    finally:
+        ops.CONV_TRACE = None
+    # the dispatch rule: full tiles pay, half-empty ones do not
+    assert lib.seam_conv3x3_f16pc_pays(48, 192, 336, 256, 256, 1) == 1
+    assert lib.seam_conv3x3_f16pc_pays(1536, 14, 14, 256, 256, 1) == 1
+    assert lib.seam_conv3x3_f16pc_pays(1536, 14, 14, 256, 256, 0) == 0      # 144 of 256 slots
+    assert lib.seam_conv3x3_f16pc_pays(48, 24, 42, 512, 512, 1) == 0        # 42 columns in 64
+    assert lib.seam_conv3x3_f16pc_pays(1, 192, 336, 256, 256, 1) == 1       # the batch size takes no part

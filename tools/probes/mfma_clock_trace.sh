@@ -1,12 +1,13 @@
 #!/bin/bash
-# Clock / power of the chip while every SIMD streams bare fp32 MFMAs (substantiate or drop the "0.85 power ceiling").
+# Clock / power of the chip while every SIMD streams bare fp32 (and, second half, fp16) MFMAs (substantiate or drop the "0.85 power ceiling").
 # usage (GPU box): tools/probes/mfma_clock_trace.sh <tag>   -> gpurun_out/<tag>_mfma_clock_trace.txt
 TAG=${1:-r05}; R=${GRAFT_REPO_ROOT:-.}; O=$R/gpurun_out; mkdir -p $O
 hipcc -O3 --offload-arch=gfx950 $R/tools/probes/pc_probe.hip -o /tmp/pc_probe 2>/dev/null || exit 1
 {
+for kind in long long16; do
 for mode in "" zero; do
-  echo "#### operands: ${mode:-random}"
-  /tmp/pc_probe long $mode > /tmp/pc_long.txt &
+  echo "#### $kind (long = fp32 32x32x2, long16 = fp16 32x32x16), operands: ${mode:-random}"
+  /tmp/pc_probe $kind $mode > /tmp/pc_long.txt &
   P=$!
   sleep 0.3
   for i in $(seq 1 12); do
@@ -15,6 +16,7 @@ for mode in "" zero; do
   done
   wait $P
   cat /tmp/pc_long.txt
+done
 done
 echo "#### idle"
 rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|power" | tr -s ' ' | tr '\n' ';'; echo

@@ -5,6 +5,7 @@
 // Build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 tools/probes/pc_probe.hip -o /tmp/pc_probe && /tmp/pc_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <string.h>
 #pragma clang diagnostic ignored "-Wunused-value"
 #include <string>
 #include <vector>
@@ -142,13 +143,32 @@ void run(const float* in, float* out, unsigned long long* stamps, const char* ta
 //                                    trace sampled beside it (tools/probes/mfma_clock_trace.sh)
 int main(int argc, char** argv) {
     const bool longrun = argc > 1 && std::string(argv[1]) == "long";
+    const bool long16 = argc > 1 && std::string(argv[1]) == "long16";    // the same with fp16 MFMAs (32x32x16)
     const bool zero = argc > 2 && std::string(argv[2]) == "zero";
     float *in, *out; unsigned long long* stamps;
     std::vector<float> h(1 << 18);
     srand(1);
     for (auto& v : h) v = zero ? 0.f : (float)rand() / RAND_MAX - 0.5f;
+    if (long16)                          // two proper fp16 values per 32-bit slot
+        for (auto& v : h) {
+            const _Float16 lo = (_Float16)v, hi = (_Float16)(zero ? 0.f : (float)rand() / RAND_MAX - 0.5f);
+            unsigned short a, b; memcpy(&a, &lo, 2); memcpy(&b, &hi, 2);
+            const unsigned u = a | ((unsigned)b << 16); memcpy(&v, &u, 4);
+        }
     hipMalloc(&in, h.size() * 4); hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&out, 256 * 512 * 4); hipMalloc(&stamps, 256 * 8 * 8);
+    if (long16) {
+        g_iters = 120000;
+        for (int rep = 0; rep < 8; ++rep) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0);
+            run<12, 2, 0, 0, 0, 0, 0, 0, 0, 1>(in, out, stamps, zero ? "bare fp16 MFMAs, zero operands" : "bare fp16 MFMAs, random operands");
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            printf("   wall %.1f ms for 2 launches -> %.1f TFLOP/s issued\n", ms, 2.0 * 256 * 4 * (double)g_iters * 48 * 32768 / (ms * 1e-3) / 1e12);
+        }
+        return 0;
+    }
     if (longrun) {
         g_iters = 60000;
         for (int rep = 0; rep < 8; ++rep) {
