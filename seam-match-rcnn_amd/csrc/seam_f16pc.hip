@@ -40,10 +40,17 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr unsigned kOob = 0x80000000u;
-constexpr int PXB = 144;                    // LDS bytes per patch pixel: 128 (64 fp16 channels) + 16 -- an odd number of 16-byte slots,
-                                            // so the 16 lanes of a ds_read_b128 phase (consecutive pixels) hit 16 different bank groups
+constexpr int PXB = 144;                    // LDS bytes per patch pixel: 128 (64 fp16 channels) + 16 -- nine 16-byte slots: consecutive pixels
+                                            // fall into consecutive-times-nine bank groups (mod 16: all different)
 constexpr int NPIXMAX = 352;                // patch pixels per buffer (8 x 32 outputs: 10 x 34 = 340)
-constexpr int PBUF = NPIXMAX * PXB;         // 50688
+constexpr int PBUF = 56 * 1024;             // bytes per patch buffer (its last 128 are the dump row of the idle producer lanes)
+// LDS pitch of a patch ROW in 16-byte slots.  The 16 lanes a ds_read_b128 serves per LDS cycle read 16 different OUTPUT slots o;
+// they are conflict free when their pixels' slot numbers differ mod 16.  Large maps: the lanes' pixels are neighbours of one
+// row.  Whole small maps: output slot o = oy * Wo + ox sits at patch pixel oy * PWi + ox -- two columns skipped per row -- so the
+// row pitch is padded to 9 Wo (mod 16), and the image pitch to 9 Ho Wo: the slot number of output o is 9 o (mod 16) again.
+// (Unpadded, the lane groups of the 8 x 8 ... 16 x 16 maps met 1.9 ... 3.0 pixels per bank group: the LDS, serving four consumer
+// waves one fragment per MFMA, was the bound of those layers -- tools/experiments/f16pc_banks.py.)
+constexpr int f16_rowp(int pwi) { return pwi == 34 ? 34 * 9 : 9 * (pwi - 2) + 32; }
 constexpr int NP = NPIXMAX * 8 / 256;       // 16-byte pieces per producer thread and chunk: 11
 constexpr int EX = PBUF;                    // LDS map: patch[2]; the finished fp16 tile (256 pixels x 256 bytes) overlays patch 1 and beyond;
 constexpr int SS = EX + 65536;              // then the tile's scale[128] | shift[128] fp32 row
@@ -51,7 +58,13 @@ constexpr int DC = SS + 1024;               // then the producers' drain count
 constexpr int LDS_BYTES = DC + 16;
 static_assert(2 * PBUF <= SS, "the finished tile must cover patch buffer 1");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
-constexpr int RB = 12;                      // B fragments in flight per consumer wave (36 steps per chunk: the ring's phase repeats every chunk)
+// 32-pixel groups of a block's tile as a function of the patch width: 8 (256 output slots) for the large maps; for the whole-map
+// form as many as the maps that fit need -- 16 x 16 inputs -> 14 x 14 outputs: 196 slots in 7 groups (8 would idle 23 % of every
+// MFMA); 14 -> 12 x 12: 144 in 5; 12 -> 10 x 10: two maps, 200 in 7; 10 -> 8 x 8: three maps, 192 in 6; 8 -> 6 x 6: five maps, 180 in 6
+constexpr int f16_nm(int pwi) { return pwi == 34 ? 8 : pwi == 16 ? 7 : pwi == 14 ? 5 : pwi == 12 ? 7 : 6; }
+// B fragments in flight per consumer wave (a divisor of the 36 steps of a chunk: the ring's phase repeats every chunk); the short
+// tiles look further ahead in steps -- the same distance in cycles
+constexpr int f16_rb(int nm) { return nm <= 6 ? 18 : 12; }
 
 #ifndef SEAM_F16PC_ABL
 #define SEAM_F16PC_ABL 0     // experiments: 1 no in-loop A fragment reads, 2 no in-loop B fragment loads, 4 no patch staging
@@ -77,6 +90,7 @@ struct F16Args {
     int G;
     int PWi, PHi;          // input patch columns / rows per image slot
     int npix;              // patch pixels per block (<= NPIXMAX)
+    int imgp;              // LDS pitch of an image slot's patch in 16-byte slots
     int bx, by;            // mode 0: patches per image along x / y
     int tiles_m, tiles_n, nchunks, total_tiles;
     unsigned m_tiles_n, m_bx, m_per_img, m_PWi, m_HoWo, m_Wo, m_slotpix;
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < 4;
+    constexpr int NM = f16_nm(PWI), RB = f16_rb(NM), ROWP = f16_rowp(PWI);
     constexpr int MODE = PWI == 34 ? 0 : 1;          // large maps in 8 x 32 patches | G whole small maps per block
     const int n = p.nchunks;
 
@@ -149,6 +164,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
         const int ptid = tid - 256;
         unsigned goff[NP];                      // global byte offset of piece (ptid & 7) of patch pixel (ptid >> 3) + 32 r; kOob outside
         LDSQ char* lp[NP];                      // its LDS address inside patch buffer 0
+        {                                       // (launch invariants; lanes past the patch write the buffer's dump row)
+            const int slotpix = p.PHi * p.PWi;
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                const int pix = (ptid >> 3) + 32 * r;
+                const int g = MODE ? fdivu(pix, slotpix, p.m_slotpix) : 0;
+                const int rm = pix - g * slotpix;
+                const int iy = fdivu(rm, p.PWi, p.m_PWi);
+                const int ix = rm - iy * p.PWi;
+                const int at = pix < p.npix ? (__mul24(g, p.imgp) + iy * ROWP + ix * 9) * 16 : PBUF - 128;
+                lp[r] = (LDSQ char*)smem + at + (ptid & 7) * 16;
+            }
+        }
         auto setup = [&](const F16Geo& q) {     // (vector ALU, beside fp16 MFMAs: the partner's VALU instructions do issue there)
             const int slotpix = p.PHi * p.PWi;
 #pragma unroll
@@ -161,7 +189,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
                 const int gy = q.y0 + iy - p.pad, gx = q.x0 + ix - p.pad;
                 const bool inb = pix < p.npix && g < q.n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
                 goff[r] = inb ? (unsigned)(__mul24(__mul24(__mul24(g, p.H) + gy, p.W) + gx, p.C) * 2 + (ptid & 7) * 16) : kOob;
-                lp[r] = (LDSQ char*)smem + (pix < NPIXMAX ? pix * PXB + (ptid & 7) * 16 : 0);
             }
         };
         auto x_desc = [&](const F16Geo& q) {
@@ -176,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
         auto store_chunk = [&](const f32x4 (&src)[NP], const int buf) {
 #pragma unroll
             for (int r = 0; r < NP; ++r)
-                if ((ptid >> 3) + 32 * r < NPIXMAX) *reinterpret_cast<f32x4 LDSQ*>(lp[r] + buf * PBUF) = src[r];
+                *reinterpret_cast<f32x4 LDSQ*>(lp[r] + buf * PBUF) = src[r];
         };
         // Chunk stream of the block: global chunk c = (tile index in the block's walk) * n + chunk-in-tile.  LDS buffer c & 1 holds
         // chunk c while the consumers multiply it; during that time chunk c + 1 goes from registers to the other buffer and chunk
@@ -237,27 +264,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
             // the tile's epilogue: the consumers' finished fp16 tile -> memory, beside the next tile's first chunk
             F16_BAR();                          // E: the tile is in LDS
             {
-                int tl = tile0 + k * S;
-                asm volatile("" : "+s"(tl));    // the 16 store offsets are computed HERE, not hoisted above the tile's chunk loop (they spilled there)
-                const F16Geo qe = f16_geo<MODE>(p, tl);
+                const F16Geo qe = f16_geo<MODE>(p, tile0 + k * S);
                 const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                     (void*)((char*)p.y + (size_t)qe.img0 * out_img), 0, (int)(out_img * qe.n_here), 0x00020000);
                 const int piece = ptid & 15;
                 const int ncol = qe.tn * 128 + piece * 8;
                 int ob = ptid >> 4;
-                asm volatile("" : "+v"(ob));    // (as above: the rows' output coordinates are launch invariants the compiler would keep live for the whole kernel)
+                asm volatile("" : "+v"(ob));    // the rows' output coordinates are launch invariants: computed HERE, not kept (spilled) for the whole kernel
 #pragma unroll
-                for (int hf = 0; hf < 4; ++hf) {
+                for (int hf = 0; hf < (2 * NM + 3) / 4; ++hf) {
                     u32x4 v[4];
                     SB();
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        if (hf * 4 + i >= 2 * NM) continue;
                         const int o = (hf * 4 + i) * 16 + ob;
                         v[i] = *reinterpret_cast<const u32x4 LDSQ*>((LDSQ char*)smem + EX + o * 256 + ((piece ^ (o & 15)) << 4));
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int it = hf * 4 + i;
+                        if (it >= 2 * NM) continue;
                         const int o = it * 16 + ob;
                         int g, oy, ox;
                         f16_slot<MODE>(p, o, g, oy, ox);
@@ -287,20 +314,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
     } else {
         // =================================================== consumer ===================================================
         const int wn = wave;                    // this wave's 32-channel n-tile of the block's 128
-        f32x16 acc[8];
+        f32x16 acc[NM];
         // per-lane LDS address of output slot 32 m + (lane & 31) at tap (0, 0), k-half (lane >> 5): constant for the whole launch
-        LDSQ char* ab[8];
+        LDSQ char* ab[NM];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < NM; ++m) {
             int g, oy, ox;
             f16_slot<MODE>(p, 32 * m + (lane & 31), g, oy, ox);
             if (MODE && 32 * m + (lane & 31) >= p.G * p.Ho * p.Wo) { g = 0; oy = 0; ox = 0; }      // idle slots read pixel 0 (never stored)
-            ab[m] = (LDSQ char*)smem + (__mul24(g, p.PHi * PWI) + oy * PWI + ox) * PXB + (lane >> 5) * 16;
+            ab[m] = (LDSQ char*)smem + (__mul24(g, p.imgp) + oy * ROWP + ox * 9) * 16 + (lane >> 5) * 16;
         }
         const int wchunk_bytes = 9 * 4 * 1024;                      // one chunk of one n-tile: 9 taps x 4 k-steps x 1 KiB
         const int wtile_bytes = n * wchunk_bytes;
         const int blane = lane * 16;
-        f32x4 af[8];                            // A fragments: the one of pixel group m at the current step, refilled right behind its MFMA
+        f32x4 af[NM];                            // A fragments: the one of pixel group m at the current step, refilled right behind its MFMA
         f32x4 bf[RB];                           // B fragments: step s in slot s % RB
         int tile = tile0;
         F16_BAR();                              // P
@@ -320,18 +347,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
             F16_TR(1);
             for (int t = 0; t < n; ++t) {
                 // this chunk's patch buffer: the lanes' pixel addresses move by one buffer (8 adds per 288 MFMAs)
-                LDSQ char* ac[8];
+                LDSQ char* ac[NM];
 #pragma unroll
-                for (int m = 0; m < 8; ++m) ac[m] = ab[m] + (t & 1) * PBUF;
+                for (int m = 0; m < NM; ++m) ac[m] = ab[m] + (t & 1) * PBUF;
                 auto read_a = [&](const int m, const int st) -> f32x4 {      // step st = tap * 4 + ks: immediate offset
-                    return *reinterpret_cast<const f32x4 LDSQ*>(ac[m] + (((st >> 2) / 3) * PWI + (st >> 2) % 3) * PXB + (st & 3) * 32);
+                    return *reinterpret_cast<const f32x4 LDSQ*>(ac[m] + (((st >> 2) / 3) * ROWP + ((st >> 2) % 3) * 9) * 16 + (st & 3) * 32);
                 };
 #pragma unroll
-                for (int m = 0; m < 8; ++m) af[m] = read_a(m, 0);
+                for (int m = 0; m < NM; ++m) af[m] = read_a(m, 0);
 #pragma unroll
                 for (int st = 0; st < 36; ++st) {
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) {
+                    for (int m = 0; m < NM; ++m) {
                         SB();
                         // roles swapped: rows = output channels (the B fragment), columns = pixels (the A fragment)
                         if (st == 0 && t == 0) {     // the tile's first step multiplies into a constant zero: no accumulator clears
@@ -373,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
                 constexpr bool RELU = decltype(relu_c)::value;
                 const f16x2 lo = f16x2{(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < NM; ++m) {
                     const int o = 32 * m + (le & 31);
                     // row o: 16 pieces of 16 bytes, piece index XOR (o & 15); rows with bit 4 set swap the 8-byte halves of a piece
                     LDSQ char* row = (LDSQ char*)smem + EX + o * 256 + ((((le >> 5) ^ (o >> 4)) & 1) << 3);
@@ -438,9 +465,12 @@ int f16pc_plan(F16Args& a, int N, int H, int W, int C, int K, int pad) {
         a.mode = 1;
         a.PWi = a.Wo + 2; a.PHi = a.Ho + 2;
         if (a.PWi != 16 && a.PWi != 14 && a.PWi != 12 && a.PWi != 10 && a.PWi != 8) return 1;
-        int g = 256 / (a.Ho * a.Wo);
-        while (g > 1 && g * a.PHi * a.PWi > NPIXMAX) --g;
-        if (g < 1 || a.PHi * a.PWi > NPIXMAX) return 1;
+        int g = 32 * f16_nm(a.PWi) / (a.Ho * a.Wo);
+        const int rowp = f16_rowp(a.PWi);
+        a.imgp = a.PHi * rowp;
+        a.imgp += ((9 * a.Ho * a.Wo - a.imgp) % 16 + 16) % 16;
+        while (g > 1 && (g * a.PHi * a.PWi > NPIXMAX || g * a.imgp * 16 > PBUF - 128)) --g;
+        if (g < 1 || a.PHi * a.PWi > NPIXMAX || a.imgp * 16 > PBUF - 128) return 1;
         a.G = g;
         a.npix = g * a.PHi * a.PWi;
         a.tiles_m = (N + g - 1) / g;
@@ -449,7 +479,7 @@ int f16pc_plan(F16Args& a, int N, int H, int W, int C, int K, int pad) {
     } else {
         if (a.Wo < 24) return 1;                // a map too narrow for 32-column patches and too large for the whole-map form
         a.mode = 0; a.G = 1;
-        a.PWi = 34; a.PHi = 10; a.npix = 340;
+        a.PWi = 34; a.PHi = 10; a.npix = 340; a.imgp = 10 * f16_rowp(34);
         a.bx = (a.Wo + 31) / 32; a.by = (a.Ho + 7) / 8;
         a.per_img = a.bx * a.by;
         a.tiles_m = N * a.per_img;
@@ -526,7 +556,7 @@ int seam_conv3x3_f16pc_supported(int N, int H, int W, int C, int K, int pad) {
 int seam_conv3x3_f16pc_pays(int N, int H, int W, int C, int K, int pad) {
     F16Args a;
     if (f16pc_plan(a, N, H, W, C, K, pad)) return 0;
-    const double slots = a.mode == 0 ? (double)a.bx * a.by * 256.0 : 256.0;
+    const double slots = a.mode == 0 ? (double)a.bx * a.by * 256.0 : 32.0 * f16_nm(a.PWi);
     const double used = a.mode == 0 ? (double)a.Ho * a.Wo : (double)a.G * a.Ho * a.Wo;
     return used >= 0.75 * slots ? 1 : 0;
 }

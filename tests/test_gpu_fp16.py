@@ -271,6 +271,6 @@ def test_conv3x3_f16pc_refuses_a_residual_and_dispatch_rule(ops):
     # the dispatch rule: full tiles pay, half-empty ones do not
     assert lib.seam_conv3x3_f16pc_pays(48, 192, 336, 256, 256, 1) == 1
     assert lib.seam_conv3x3_f16pc_pays(1536, 14, 14, 256, 256, 1) == 1
-    assert lib.seam_conv3x3_f16pc_pays(1536, 14, 14, 256, 256, 0) == 0      # 144 of 256 slots
+    assert lib.seam_conv3x3_f16pc_pays(1536, 14, 14, 256, 256, 0) == 1      # 144 slots of a 160-slot tile
     assert lib.seam_conv3x3_f16pc_pays(48, 24, 42, 512, 512, 1) == 0        # 42 columns in 64
     assert lib.seam_conv3x3_f16pc_pays(1, 192, 336, 256, 256, 1) == 1       # the batch size takes no part
