@@ -531,6 +531,8 @@ def mfma_issue_ratio(variant):
         return 1.0 / 2.25, "Winograd F(2x2,3x3): 16 MFMA multiplies per 2x2 output tile and channel pair instead of 36"
     if variant.startswith("conv_igemm_bx3"):
         return 3.0, "split-bf16: 3 bf16 MFMAs per fp32 product (hi*hi + hi*lo + lo*hi)"
+    if variant.startswith("conv3x3_f16pc"):
+        return 1.0, "direct 3x3 convolution, input patch staged in LDS: one MFMA multiply per algorithmic multiply"
     if variant.startswith("conv1x1_sw"):
         return 1.0, "weights-stationary pointwise GEMM: one MFMA multiply per algorithmic multiply"
     return 1.0, "implicit GEMM: one MFMA multiply per algorithmic multiply"
@@ -569,20 +571,27 @@ def roofline_leg(step, dtype):
     peak = FP32_MFMA_PEAK_TFLOPS if dtype == "f32" else F16_MFMA_PEAK_TFLOPS
     issue, algo = mfma_issue_ratio(dom)
     achieved = algorithmic * issue
-    src, traffic, busy = pmc_fields(dom) if dtype == "f32" else (None, None, None)
+    src, traffic, busy, clock = pmc_fields(dom, dtype)
 
     def rate(v):
         return round(v[1] / v[2] / 1e12, 2)
 
+    extra = {}
+    if dtype == "f16":
+        # frac stays against the nominal dense peak; what the chip sustains on this instruction is measured separately
+        extra["sustained_mfma_tflops_measured"] = {
+            "dense_random_operands": 1760.0, "zero_operands": 2492.0,
+            "source": "profiles/r05_mfma_clock_trace.txt: bare v_mfma_f32_32x32x16_f16 on every SIMD, operands in registers -- "
+                      "the 1300 W package limit holds the clock at 1.72 GHz on dense random operands (2.40 GHz / 842 W on zeros)"}
     return {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4),
+            "frac": round(achieved / peak, 4), **extra,
             "achieved_is": "MFMA FLOP/s issued for the algorithmic work = algorithmic_tflops x mfma_issue_ratio "
                            "(unfilled tile slots are not counted as work)",
             "measured_on": "one instrumented step on a single stream (= bench.py --single-stream; the timed steps run two streams)",
             "algorithm": algo, "mfma_issue_ratio": round(issue, 4),
             "algorithmic_tflops": round(algorithmic, 2),
             "algorithmic_flops_are": "2*M*K*R*S*C of the direct convolution per launch (SURVEY.md 8d)",
-            "traffic": traffic, "mfma_busy_frac_pmc": busy,
+            "traffic": traffic, "mfma_busy_frac_pmc": busy, "clock_ghz_pmc": clock,
             "pmc_source": src,
             "algorithmic_bytes_per_launch": round(alg_bytes / n),
             "launches_per_step": n, "avg_launch_us": round(1e6 * sec / n, 2),
@@ -606,27 +615,33 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
-def pmc_fields(kernel):
-    """(source, traffic, mfma_busy) of `kernel` from the newest COMMITTED rocprofv3 PMC passes (profiles/*_pmc_traffic.json, made
+def pmc_fields(kernel, dtype="f32"):
+    """(source, traffic, mfma_busy, clock GHz) of `kernel` from the newest COMMITTED rocprofv3 PMC passes (profiles/*_pmc_traffic.json;
+    the fp16 config-5 passes: profiles/*_f16_pmc_traffic.json, made
     by tools/pmc_bench_traffic.sh over this same bench command on an earlier run -- NOT measured in this process; `source`
     names the file so that a reader can tell).  traffic = HBM-side bytes per launch: FETCH_SIZE and WRITE_SIZE are collected in
     separate passes and reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads, so the read
     side is doubled (MI355X_MICROARCH.md, HBM section).  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None, None, None
-    traffic = busy = None
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))
+                   if f.endswith("_f16_pmc_traffic.json") == (dtype == "f16"))
+    if not files or dtype not in ("f32", "f16"):
+        return None, None, None, None
+    traffic = busy = clock = None
     try:
         d = json.load(open(files[-1]))
     except (ValueError, OSError):
-        return None, None, None
+        return None, None, None, None
     try:
         traffic = round((2.0 * d["FETCH_SIZE"][kernel]["avg_per_launch"] + d["WRITE_SIZE"][kernel]["avg_per_launch"]) * 1024)
     except KeyError:
         pass
     try:
         busy = d["mfma_busy_frac"][kernel]
+    except KeyError:
+        pass
+    try:
+        clock = d["clock_ghz"][kernel]
     except KeyError:
         pass
     src = {"file": os.path.relpath(files[-1], ROOT), "measured_in_this_run": False,
@@ -639,8 +654,8 @@ def pmc_fields(kernel):
     src["matches_current_sources"] = src.get("csrc_digest") == src["csrc_digest_now"]
     if not src["matches_current_sources"]:
         src["stale"] = "collected on different kernel sources: traffic / mfma_busy_frac_pmc withheld (re-run tools/pmc_bench_traffic.sh)"
-        traffic = busy = None
-    return src, traffic, busy
+        traffic = busy = clock = None
+    return src, traffic, busy, clock
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline + parity

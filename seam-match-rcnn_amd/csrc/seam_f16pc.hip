@@ -5,16 +5,17 @@
 // 0.44, profiles/r05_f16_pmc_traffic.json): every one of the nine taps gathers its own [256 pixels x 64 channels] A tile from
 // global memory -- the same input pixel nine times, at a 1-KiB stride -- through the same in-order vmcnt queue as the weights, and
 // the eight waves of a block meet at a barrier per tap and chunk.  Here:
-//   * a block owns 256 output pixels x 128 output channels: a 8 x 32 patch of a large map, or G whole small maps (the ROI-sized
-//     layers: 14x14, 10x10, 8x8, 6x6 outputs);
+//   * a block owns up to 256 output pixels x 128 output channels: a 8 x 32 patch of a large map, or G whole small maps (the
+//     ROI-sized layers: 14x14, 12x12, 10x10, 8x8, 6x6 outputs) in as many 32-pixel groups as they need (5..7: f16_nm);
 //   * waves 4..7 (producers) stage the INPUT PATCH -- (rows + 2) x (columns + 2) pixels x 64 channels, one full 128-byte line per
 //     pixel, eight adjacent lanes per line -- into LDS once per 64-channel chunk (double buffered, one chunk ahead in LDS, one more
 //     in registers), across tile boundaries; they never touch the vector ALU in steady state;
-//   * waves 0..3 (consumers, one per SIMD) only multiply: wave w owns output channels 32 w .. 32 w + 31 of the block for ALL 256
-//     pixels (8 accumulator tiles = 128 registers).  Per MFMA one `ds_read_b128` takes the A fragment of one 32-pixel group at
+//   * waves 0..3 (consumers, one per SIMD) only multiply: wave w owns output channels 32 w .. 32 w + 31 of the block for ALL its
+//     pixels (up to 8 accumulator tiles = 128 registers).  Per MFMA one `ds_read_b128` takes the A fragment of one 32-pixel group at
 //     one tap straight out of the patch (address = the lane's pixel + an immediate tap offset: the nine taps re-read LDS, not
 //     memory); per eight MFMAs one 1-KiB global load takes the wave's own B fragment (weights packed in fragment order) through
-//     a register ring.  One barrier per chunk (288 MFMAs per wave = 9216 cycles).
+//     a register ring.  One barrier per chunk (288 MFMAs per wave = 9216 cycles).  The patch rows of the small maps are padded
+//     so that the 16 lanes of an LDS cycle meet 16 different bank groups (f16_rowp).
 //   * epilogue: the consumers finish their own accumulators in registers (pixels in lanes, four consecutive channels per register
 //     quad -- the MFMA's operand roles are swapped; the tile's scale / shift vectors come from a 1-KiB LDS row the producers
 //     filled during the last chunk): fp32 scale / shift, fp16 rounding, ReLU, then 8-byte swizzled writes of the whole
@@ -23,6 +24,9 @@
 //     finishing arithmetic).  The producers drain the tile to memory (16-byte NHWC stores) beside that chunk's MFMAs.
 //     (The first form went through fp32 exchange rows in four passes of two barriers, all 512 threads finishing: 7.9 k of a
 //     tile's 50 k cycles, profiles/r05_f16pc_trace.txt.)  A residual operand is not taken: no 3x3 layer of the path has one.
+// Measured (profiles/r05_f16pc_ab.txt, r05_f16pc_pmc.txt, r05_f16pc_ablation.txt): 1.29-1.49x the implicit GEMM on every config-5
+// 3x3 shape whose tiles are >= 3/4 full; 192 x 336 x 256 -> 256: 1.2 PFLOP/s, matrix pipe busy 0.845 -- at 1.50 GHz: the 1300 W
+// package limit, not the issue rate, bounds it (bare MFMAs out of registers sustain 1.76 PFLOP/s at 1.72 GHz on dense operands).
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <stdint.h>

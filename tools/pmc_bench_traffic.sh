@@ -5,7 +5,7 @@
 # Output: gpurun_out/pmc_traffic_<tag>.json  (per-launch averages; FETCH/WRITE in KiB as reported by rocprofv3)
 TAG=${1:-r01}; shift
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
-PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16")
+PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16")
 i=0
 for c in "${PASSES[@]}"; do
   rm -rf /tmp/pmc_$i
@@ -26,6 +26,10 @@ for i in range($i):
             mm = re.search(r"conv3x3_wino24<(\d+)>", r["Kernel_Name"])
             key = "conv3x3_wino24pc" if "conv3x3_wino24pc" in r["Kernel_Name"] else f"conv3x3_wino24<{mm.group(1)}>" if mm else "conv3x3_wino24"
             a = agg[r["Counter_Name"]][key]
+            a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            continue
+        if "conv3x3_f16pc" in r["Kernel_Name"]:
+            a = agg[r["Counter_Name"]]["conv3x3_f16pc"]
             a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             continue
         ms = re.search(r"pw_sw_kernel<(\d+), *(\d+)", r["Kernel_Name"])
@@ -52,11 +56,14 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "SQ_BUSY_CU_CYCLES" in out:
     # matrix-pipe busy fraction while the CU is busy: MFMA busy cycles are counted per SIMD (4 per CU)
     out["mfma_busy_frac"] = {k: round(out["SQ_VALU_MFMA_BUSY_CYCLES"][k]["total"] / (4.0 * out["SQ_BUSY_CU_CYCLES"][k]["total"]), 4)
                              for k in out["SQ_VALU_MFMA_BUSY_CYCLES"] if k in out["SQ_BUSY_CU_CYCLES"]}
+if "GRBM_GUI_ACTIVE" in out:
+    # shader clock while the kernel ran: GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles
+    out["clock_ghz"] = {k: round(v["total"] / 8.0 / (v["avg_us"] * v["launches"]) / 1e3, 3) for k, v in out["GRBM_GUI_ACTIVE"].items()}
 import subprocess, datetime, sys
 sys.path.insert(0, "$R")
 import bench
 out["_meta"] = {"tag": "$TAG", "csrc_digest": bench.csrc_digest(), "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
-                "command": "rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --single-stream"}
+                "command": "rocprofv3 --kernel-trace --pmc <one pass per counter group> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --single-stream $*"}
 json.dump(out, open("$R/gpurun_out/pmc_traffic_$TAG.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k in ("mfma_busy_frac",)}, indent=1))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
