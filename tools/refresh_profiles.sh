@@ -38,4 +38,8 @@ bash $R/tools/pmc_bench_traffic.sh ${TAG}_f16 --workload c5 --dtype f16 > $O/${T
 hipcc -O3 --offload-arch=gfx950 $R/tools/probes/pc_probe.hip -o /tmp/pc_probe 2>/dev/null && /tmp/pc_probe > $O/${TAG}_pc_probe.txt 2>&1
 bash $R/tools/probes/mfma_clock_trace.sh $TAG > /dev/null 2>&1
 bash $R/tools/w24pc_ab.sh $TAG > /dev/null 2>&1
+# conv3x3_f16pc vs the fp16 implicit GEMM on the config-5 3x3 shapes (whole-batch reference), the big layer on post-ReLU / zero inputs
+# (operand statistics move the power-capped clock), and its counters
+{ python3 $R/tools/f16pc_ab.py --full; python3 $R/tools/f16pc_ab.py --relu-input 48,192,336,256,256,1; python3 $R/tools/f16pc_ab.py --zeros 48,192,336,256,256,1; } 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_f16pc_ab.txt
+bash $R/tools/pmc_f16pc.sh 48,192,336,256,256,1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES > $O/${TAG}_f16pc_pmc.txt 2>&1
 ls -la $O | grep $TAG
