@@ -94,6 +94,10 @@ int seam_conv2d_upres_f32(const float* x, const float* w_packed, const float* sc
 int seam_conv2d_crop_f32(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
                          int relu, seam_stream_t stream);
+/* fp16 twin (operands fp16, fp32 accumulate): the stem of the fp16 path on seam_preprocess_s2d_batch_f16's 16-channel cells. */
+int seam_conv2d_crop_f16(const void* x, const void* w_packed, const float* scale, const float* shift, void* y,
+                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
+                         int relu, seam_stream_t stream);
 
 /* ResNet downsample blocks [TV Bottleneck.forward: out = relu(bn3(conv3(h)) + bn_d(conv_d(x)))] as ONE GEMM over two 1x1
  * sources: y[n,ho,wo,:] = act(W[:, :C1] . x1[n,ho,wo,:] + W[:, C1:] . x2[n,ho*stride2,wo*stride2,:] (* scale) + shift).
@@ -159,6 +163,9 @@ int seam_preprocess_batch_f16(const float* imgs, size_t img_stride, void* out, i
 /* The same transform written space-to-depth for the stem: out [n, Hp/2, Wp/2, 12], channel (dy*2+dx)*3 + c = pixel
  * (2Y+dy, 2X+dx), colour c (Hp, Wp even). */
 int seam_preprocess_s2d_batch_f32(const float* imgs, size_t img_stride, float* out, int n, int in_h, int in_w,
+                                  int out_h, int out_w, int Hp, int Wp, seam_stream_t stream);
+/* fp16 output: [n, Hp/2, Wp/2, 16] -- the 12 channels above + 4 zeros (the fp16 GEMM reads 8-channel vectors). */
+int seam_preprocess_s2d_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w,
                                   int out_h, int out_w, int Hp, int Wp, seam_stream_t stream);
 
 /* Same transform fed by a uint8 HWC RGB frame [in_h,in_w,3]: fuses ToTensor (x/255, stuffs/transform.py:46-49)

@@ -42,7 +42,9 @@ SIGNATURES = {
     "seam_pack_linear_narrow_f32": (_i, [_p, _p, _i, _i, _p]),
     "seam_linear_narrow_f32": (_i, [_p, _p, _p, _p, C.c_longlong, _i, _i, _i, _p]),
     "seam_conv2d_crop_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv2d_crop_f16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_s2d_batch_f32": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_preprocess_s2d_batch_f16": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv1x1_sw_config": (_i, [_i, _i, _i, _i]),
     "seam_conv1x1_sw_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -1163,6 +1163,12 @@ int seam_conv2d_crop_f32(const float* x, const float* w_packed, const float* sca
     return conv2d<float>(x, w_packed, scale, shift, nullptr, y, N, H, W, C, K, R, S, stride, pad, relu, 1, stream, 0, 0, nullptr, Ho, Wo);
 }
 
+int seam_conv2d_crop_f16(const void* x, const void* w_packed, const float* scale, const float* shift, void* y, int N, int H, int W,
+                         int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int relu, void* stream) {
+    if (Ho <= 0 || Wo <= 0) return (int)hipErrorInvalidValue;
+    return conv2d<_Float16>(x, w_packed, scale, shift, nullptr, y, N, H, W, C, K, R, S, stride, pad, relu, 0, stream, 0, 0, nullptr, Ho, Wo);
+}
+
 int seam_conv2d_dual_f16(const void* x1, const void* x2, const void* w_packed, const float* scale, const float* shift, void* y,
                          int N, int Ho, int Wo, int C1, int H2, int W2, int C2, int stride2, int K, int relu, void* stream) {
     const DualSrc d = {x2, H2, W2, C2, stride2};

@@ -109,11 +109,21 @@ __global__ void preprocess_s2d_kernel(const float* __restrict__ img, T* __restri
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[d * 3 + c] = v[c];
     }
-    T* dst = out + (((size_t)blockIdx.z * H2 + Y) * W2 + X) * 12;
+    if constexpr (sizeof(T) == 2) {             // fp16: 16 channels per cell (12 + 4 zeros: the fp16 GEMM reads 8-channel vectors), 32 bytes
+        typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+        T* dst = out + (((size_t)blockIdx.z * H2 + Y) * W2 + X) * 16;
+        h16x8 a, b;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        f32x4 v4 = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(dst + 4 * q) = v4;
+        for (int c = 0; c < 8; ++c) { a[c] = (_Float16)o[c]; b[c] = (_Float16)(c < 4 ? o[8 + c] : 0.f); }
+        *reinterpret_cast<h16x8*>(dst) = a;
+        *reinterpret_cast<h16x8*>(dst + 8) = b;
+    } else {
+        T* dst = out + (((size_t)blockIdx.z * H2 + Y) * W2 + X) * 12;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            f32x4 v4 = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(dst + 4 * q) = v4;
+        }
     }
 }
 
@@ -324,6 +334,15 @@ int seam_preprocess_s2d_batch_f32(const float* imgs, size_t img_stride, float* o
     dim3 grid((Wp / 2 + 127) / 128, Hp / 2, n);
     hipLaunchKernelGGL(preprocess_s2d_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, imgs, out, in_h, in_w, out_h, out_w,
                        Hp, Wp, img_stride);
+    return (int)hipGetLastError();
+}
+
+int seam_preprocess_s2d_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w, int out_h, int out_w,
+                                  int Hp, int Wp, void* stream) {
+    if (n < 1 || n > 65535 || (Hp & 1) || (Wp & 1)) return (int)hipErrorInvalidValue;
+    dim3 grid((Wp / 2 + 127) / 128, Hp / 2, n);
+    hipLaunchKernelGGL(preprocess_s2d_kernel<_Float16>, grid, dim3(128), 0, (hipStream_t)stream, imgs, (_Float16*)out, in_h, in_w,
+                       out_h, out_w, Hp, Wp, img_stride);
     return (int)hipGetLastError();
 }
 

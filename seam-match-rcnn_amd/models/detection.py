@@ -80,8 +80,8 @@ class GeneralizedRCNNTransform(nn.Module):
         d = self.size_divisible
         hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
         wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
-        # exact-fp32 path with float images: space-to-depth layout for the 4x4 / stride-1 form of the stem (STEM_S2D)
-        s2d = STEM_S2D and cdt(self) == torch.float32 and all(i.dtype == torch.float32 for i in images)
+        # fp32 / fp16 paths with float images: space-to-depth layout for the 4x4 / stride-1 form of the stem (STEM_S2D)
+        s2d = STEM_S2D and cdt(self) in (torch.float32, torch.float16) and all(i.dtype == torch.float32 for i in images)
         return ops.preprocess(images, sizes, hp, wp, adt(self), s2d=s2d), sizes, orig, (hp, wp)
 
     @staticmethod
@@ -164,12 +164,12 @@ class ResNet50Body(nn.Module):
             with torch.no_grad():
                 pk = {"stem": ops.pack_conv(self.conv1.weight, None, self.bn1.tensors(), stride=2, pad=3,
                                             cstore=8 if dt == torch.float16 else 4, bn_eps=self.bn1.eps, dtype=dt)}
-                if dt == torch.float32:
+                if dt in (torch.float32, torch.float16):
                     # w'[k, (dy*2+dx)*3 + c, r', s'] = w[k, c, 2r'+dy-1, 2s'+dx-1]  (zero where the 7x7 kernel has no tap)
                     w8 = F.pad(self.conv1.weight.detach().to(torch.float32), (1, 0, 1, 0))          # [64,3,8,8], index 0 = tap -1
                     ws = w8.view(64, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(64, 12, 4, 4).contiguous()
-                    pk["stem_s2d"] = ops.pack_conv(ws, None, self.bn1.tensors(), stride=1, pad=2, cstore=12, bn_eps=self.bn1.eps,
-                                                   wino=False)
+                    pk["stem_s2d"] = ops.pack_conv(ws, None, self.bn1.tensors(), stride=1, pad=2, cstore=12 if dt == torch.float32 else 16,
+                                                   bn_eps=self.bn1.eps, wino=False, dtype=dt)
                 for li in range(1, 5):
                     for bi, b in enumerate(getattr(self, f"layer{li}")):
                         e = {"c1": ops.pack_conv(b.conv1.weight, None, b.bn1.tensors(), bn_eps=b.bn1.eps, dtype=dt),
@@ -198,7 +198,7 @@ class ResNet50Body(nn.Module):
             if (getattr(self, "_streams", None) is None or len(self._streams) != BODY_STREAMS
                     or self._streams[0].device != x.device):            # rebuilt after model.to(another device)
                 self._streams = [torch.cuda.Stream(device=x.device) for _ in range(BODY_STREAMS)]
-            h1, w1 = ((x.shape[1], x.shape[2]) if x.shape[-1] == 12 else
+            h1, w1 = ((x.shape[1], x.shape[2]) if x.shape[-1] in (12, 16) else
                       ((x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1))
             hh, ww = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
             outs = []
@@ -218,7 +218,7 @@ class ResNet50Body(nn.Module):
         return self._run(x, pk, None)
 
     def _run(self, x, pk, outs):
-        if x.shape[-1] == 12:      # space-to-depth input [N,H/2,W/2,12]: the stem as a 4x4 / stride-1 conv, output grid = input grid
+        if x.shape[-1] in (12, 16):    # space-to-depth input [N,H/2,W/2,12] (fp16: 16): the stem as a 4x4 / stride-1 conv, output grid = input grid
             x = ops.conv2d(x, pk["stem_s2d"], relu=True, out_hw=(x.shape[1], x.shape[2]))
         else:
             x = ops.conv2d(x, pk["stem"], relu=True)           # 7x7/s2 + FrozenBN + ReLU

@@ -394,8 +394,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     ho = (h + 2 * pc.pad - pc.R) // pc.stride + 1
     wo = (w + 2 * pc.pad - pc.S) // pc.stride + 1
     if out_hw is not None:      # top-left crop of the output grid (``seam_conv2d_crop_f32``: the space-to-depth stem)
-        if pc.dtype != F32 or residual is not None or out_hw[0] > ho or out_hw[1] > wo:
-            raise ValueError("conv2d: out_hw needs exact-fp32 weights, no residual and a size inside the full output")
+        if pc.dtype not in (F32, F16) or out_f32 or residual is not None or out_hw[0] > ho or out_hw[1] > wo:
+            raise ValueError("conv2d: out_hw needs fp32 or fp16 weights, no residual and a size inside the full output")
         ho, wo = int(out_hw[0]), int(out_hw[1])
     narrow = pc.wn is not None and NARROW and residual is None and out_hw is None
     ydt = F32 if (pc.dtype != F16 or out_f32) else F16
@@ -429,9 +429,10 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     elif wino:
         _native.check(lib.seam_conv3x3_wino_f32(_ptr(x), _ptr(pc.u), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                                 n, h, w, c, pc.K, pc.pad, int(relu), _stream()), "seam_conv3x3_wino_f32")
-    elif pc.dtype == F32 and out_hw is not None:
-        _native.check(lib.seam_conv2d_crop_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, h, w, c, pc.K,
-                                               pc.R, pc.S, pc.stride, pc.pad, ho, wo, int(relu), _stream()), "seam_conv2d_crop_f32")
+    elif out_hw is not None:            # (fp32 or fp16: checked above)
+        crop = lib.seam_conv2d_crop_f16 if pc.dtype == F16 else lib.seam_conv2d_crop_f32
+        _native.check(crop(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, h, w, c, pc.K,
+                           pc.R, pc.S, pc.stride, pc.pad, ho, wo, int(relu), _stream()), "seam_conv2d_crop")
     elif pc.dtype == F32:
         _native.check(lib.seam_conv2d_f32(_ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                           n, h, w, c, pc.K, pc.R, pc.S, pc.stride, pc.pad, int(relu), _stream()),
@@ -605,7 +606,8 @@ def _sfx(dtype) -> str:
 
 def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, wp: int, dtype=F32, s2d: bool = False) -> torch.Tensor:
     """normalise + resize + pad + CHW->NHWC for a list of fp32 images -> [N,hp,wp,4] fp32 / [N,hp,wp,8] fp16.
-    ``s2d`` (fp32 [3,H,W] images only): the space-to-depth layout [N,hp/2,wp/2,12] of ``seam_preprocess_s2d_batch_f32``."""
+    ``s2d`` (fp32 [3,H,W] images only): the space-to-depth layout [N,hp/2,wp/2,12] of ``seam_preprocess_s2d_batch_f32``
+    (fp16: [N,hp/2,wp/2,16], four zero channels, ``_f16``)."""
     lib = _native.lib()
     # device check FIRST, for every image and every branch below: a CPU tensor must raise SeamNativeError, never reach a
     # kernel as a raw host pointer (the one-launch batch branches take data_ptr() of the views directly)
@@ -613,23 +615,24 @@ def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, 
     if not images:
         raise ValueError("preprocess: empty image list")
     if s2d:
-        if dtype != F32 or hp % 2 or wp % 2 or any(i.dtype != F32 or i.dim() != 3 or i.shape[0] != 3 for i in images):
+        if dtype not in (F32, F16) or hp % 2 or wp % 2 or any(i.dtype != F32 or i.dim() != 3 or i.shape[0] != 3 for i in images):
             raise ValueError("preprocess(s2d=True): fp32 [3,H,W] images and an even padded size")
         n = len(images)
-        out = torch.empty((n, hp // 2, wp // 2, 12), dtype=F32, device=images[0].device)
+        out = torch.empty((n, hp // 2, wp // 2, 12 if dtype == F32 else 16), dtype=dtype, device=images[0].device)
+        s2d_fn = lib.seam_preprocess_s2d_batch_f32 if dtype == F32 else lib.seam_preprocess_s2d_batch_f16
         same = n <= 65535 and all(i.shape == images[0].shape and i.is_contiguous() for i in images) \
             and all(tuple(z) == tuple(sizes[0]) for z in sizes)
         p0 = images[0].data_ptr()
         step = (images[1].data_ptr() - p0) if n > 1 else 0
         if same and n > 1 and step > 0 and step % 4 == 0 and all(im.data_ptr() == p0 + k * step for k, im in enumerate(images)):
-            _native.check(lib.seam_preprocess_s2d_batch_f32(C.c_void_p(p0), step // 4, _ptr(out), n, images[0].shape[1],
+            _native.check(s2d_fn(C.c_void_p(p0), step // 4, _ptr(out), n, images[0].shape[1],
                                                             images[0].shape[2], sizes[0][0], sizes[0][1], hp, wp, _stream()),
-                          "seam_preprocess_s2d_batch_f32")
+                          "seam_preprocess_s2d_batch")
             return out
         for i, (img, (oh, ow)) in enumerate(zip(images, sizes)):
             img = _req(img, name="image")
-            _native.check(lib.seam_preprocess_s2d_batch_f32(_ptr(img), 0, C.c_void_p(out[i].data_ptr()), 1, img.shape[1], img.shape[2],
-                                                            oh, ow, hp, wp, _stream()), "seam_preprocess_s2d_batch_f32")
+            _native.check(s2d_fn(_ptr(img), 0, C.c_void_p(out[i].data_ptr()), 1, img.shape[1], img.shape[2],
+                                                            oh, ow, hp, wp, _stream()), "seam_preprocess_s2d_batch")
         return out
     cs = 4 if dtype == F32 else 8
     out = torch.empty((len(images), hp, wp, cs), dtype=dtype, device=images[0].device)

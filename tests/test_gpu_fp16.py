@@ -274,3 +274,38 @@ def test_conv3x3_f16pc_refuses_a_residual_and_dispatch_rule(ops):
     assert lib.seam_conv3x3_f16pc_pays(1536, 14, 14, 256, 256, 0) == 1      # 144 slots of a 160-slot tile
     assert lib.seam_conv3x3_f16pc_pays(48, 24, 42, 512, 512, 1) == 0        # 42 columns in 64
     assert lib.seam_conv3x3_f16pc_pays(1, 192, 336, 256, 256, 1) == 1       # the batch size takes no part
+
+
+@pytest.mark.parametrize("hw", [(64, 96), (70, 100)])
+def test_stem_space_to_depth_f16(ops, hw):
+    """fp16 twin of tests/test_gpu_ops.py::test_stem_space_to_depth: preprocess -> [N,H/2,W/2,16] fp16 (12 channels + 4 zeros), the stem
+    as a 4x4 / stride-1 conv with re-indexed weights and a cropped output grid == the oracle's transform + 7x7 / stride-2 conv +
+    FrozenBN + ReLU to fp16 accuracy, and == the 8-channel fp16 form to its rounding."""
+    d = dev()
+    h, w = hw
+    from seam_match_rcnn_amd.models.detection import resized_size
+    clip = torch.from_numpy(synth.uniform(synth.stream_id(80, "clip"), (3, 3, h, w)))
+    imgs = list(clip.to(d).unbind(0))
+    ref_in, sizes = OD.transform(list(clip.unbind(0)), min_size=96, max_size=160)
+    hp, wp = ref_in.shape[-2:]
+    sz = [resized_size(h, w, 96, 160)[:2]] * 3
+    wt = rnd(81, (64, 3, 7, 7), "w") / (147 ** 0.5)
+    bnp = (torch.from_numpy(synth.uniform(synth.stream_id(82, "bw"), (64,), 0.5, 1.5)), rnd(83, (64,), "bb") * 0.1,
+           rnd(84, (64,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(85, "rv"), (64,), 0.5, 1.5)))
+    sc = bnp[0] * (bnp[3] + 1e-5).rsqrt()
+    ref = F.relu(F.conv2d(ref_in, wt, None, 2, 3) * sc[None, :, None, None] + (bnp[1] - bnp[2] * sc)[None, :, None, None])
+    x16 = ops.preprocess(imgs, sz, hp, wp, H, s2d=True)
+    assert x16.shape == (3, hp // 2, wp // 2, 16) and x16.dtype == H
+    x8 = ops.preprocess(imgs, sz, hp, wp, H)
+    back = x16[..., :12].reshape(3, hp // 2, wp // 2, 2, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(3, hp, wp, 3)
+    assert torch.equal(back, x8[..., :3]) and float(x16[..., 12:].abs().max()) == 0.0
+    w8 = F.pad(wt, (1, 0, 1, 0))
+    ws = w8.view(64, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(64, 12, 4, 4).contiguous()
+    bn_d = tuple(t.to(d) for t in bnp)
+    pc16 = ops.pack_conv(ws.to(d), None, bn_d, stride=1, pad=2, cstore=16, wino=False, dtype=H)
+    got = ops.conv2d(x16, pc16, relu=True, out_hw=(hp // 2, wp // 2))
+    assert got.dtype == H
+    assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=4e-3, atol_scale=2e-3)
+    pc8 = ops.pack_conv(wt.to(d), None, bn_d, stride=2, pad=3, cstore=8, dtype=H)
+    old = ops.conv2d(x8, pc8, relu=True)
+    assert old.shape == got.shape and float((old.float() - got.float()).abs().max()) <= 2e-3 * float(old.float().abs().max())

@@ -3,12 +3,17 @@
 # usage: tools/refresh_profiles.sh <tag>      (ONE generation per round, on the final tree; the frozen bf16x3 experiment is not refreshed)
 TAG=${1:-r01}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp
+# counters first: bench.py attaches traffic / pipe-busy / clock from profiles/<tag>[_f16]_pmc_traffic.json when its csrc digest
+# matches the tree -- so the lines below carry the counters of THIS generation (copy the two JSONs into profiles/ afterwards)
+bash $R/tools/pmc_bench_traffic.sh $TAG > $O/${TAG}_pmc.log 2>&1
+cp $O/pmc_traffic_$TAG.json $R/profiles/${TAG}_pmc_traffic.json
+bash $R/tools/pmc_bench_traffic.sh ${TAG}_f16 --workload c5 --dtype f16 > $O/${TAG}_f16_pmc.log 2>&1
+cp $O/pmc_traffic_${TAG}_f16.json $R/profiles/${TAG}_f16_pmc_traffic.json
 python3 $R/bench.py > $O/${TAG}_bench.json 2>$O/${TAG}_bench.err
 rm -rf /tmp/prof_$TAG
 # kernel stats of the 8-clip steps only: --no-extras keeps the one-clip / full-forward legs (same kernels, other sizes) out of the averages
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o b -- python3 $R/bench.py --no-cpu-baseline --no-extras --single-stream > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
 cp /tmp/prof_$TAG/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null || cp /tmp/prof_$TAG/*/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
-bash $R/tools/pmc_bench_traffic.sh $TAG > $O/${TAG}_pmc.log 2>&1
 python3 $R/bench.py --workload c3 --no-roofline --cpu-runs 1 > $O/${TAG}_bench_c3.json 2>/dev/null
 python3 $R/bench.py --workload c4 --no-roofline --no-cpu-baseline > $O/${TAG}_bench_c4.json 2>/dev/null
 python3 $R/bench.py --dtype f16 --no-cpu-baseline > $O/${TAG}_bench_f16.json 2>/dev/null
@@ -32,8 +37,6 @@ python3 $R/tools/full_forward_timing.py > $O/${TAG}_full_forward.txt 2>/dev/null
 rm -rf /tmp/ff_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ff_$TAG -o f -- python3 $R/tools/full_forward_timing.py > /dev/null 2>&1
 (cat /tmp/ff_$TAG/f_kernel_stats.csv 2>/dev/null || cat /tmp/ff_$TAG/*/f_kernel_stats.csv) > $O/${TAG}_full_forward_kernel_stats.csv
-# counters of the fp16 config-5 path (the evidence was missing)
-bash $R/tools/pmc_bench_traffic.sh ${TAG}_f16 --workload c5 --dtype f16 > $O/${TAG}_f16_pmc.log 2>&1
 # the probes behind DESIGN section 3: partner-wave experiments and the clock / power trace of bare fp32 MFMAs
 hipcc -O3 --offload-arch=gfx950 $R/tools/probes/pc_probe.hip -o /tmp/pc_probe 2>/dev/null && /tmp/pc_probe > $O/${TAG}_pc_probe.txt 2>&1
 bash $R/tools/probes/mfma_clock_trace.sh $TAG > /dev/null 2>&1
