@@ -533,6 +533,8 @@ def mfma_issue_ratio(variant):
         return 3.0, "split-bf16: 3 bf16 MFMAs per fp32 product (hi*hi + hi*lo + lo*hi)"
     if variant.startswith("conv3x3_f16pc"):
         return 1.0, "direct 3x3 convolution, input patch staged in LDS: one MFMA multiply per algorithmic multiply"
+    if variant.startswith("conv1x1_pc"):
+        return 1.0, "producer / consumer pointwise GEMM (long reductions): one MFMA multiply per algorithmic multiply"
     if variant.startswith("conv1x1_sw"):
         return 1.0, "weights-stationary pointwise GEMM: one MFMA multiply per algorithmic multiply"
     return 1.0, "implicit GEMM: one MFMA multiply per algorithmic multiply"

@@ -123,6 +123,20 @@ int seam_conv1x1_sw_f32(const float* x, const float* x2, const float* w, const f
                         int M, int C1, int C2, int K, int relu, int res_mode, int Ho, int Wo, int rH, int rW,
                         seam_stream_t stream);
 
+/* Pointwise (1x1, stride 1, pad 0) convolution with a LONG reduction as producer / consumer waves (csrc/seam_pwpc.hip, round 5):
+ * the bottleneck reductions of ResNet layer2-4 and the layer4 expansions [TV Bottleneck conv1 / conv3 behind
+ * models/video_matchrcnn.py:337], exact fp32 on v_mfma_f32_32x32x2_f32, the same contract as seam_conv2d_f32 on those shapes:
+ *   y[M,K] = act( x[M,C] . W[K,C]^T * scale + shift [+ residual[M,K]] )
+ * Shapes served (seam_conv1x1_pc_supported): C >= 256 and a multiple of 128, K a multiple of 128, any M > 0.  Weights:
+ * seam_conv1x1_pc_weight_floats(K, C) floats from seam_pack_conv1x1_pc_f32 (row-major [K, C] in; MFMA fragment order).  scale /
+ * shift [K] or NULL.  An output is one wave's fixed fma chain over k: results are deterministic and independent of M; they differ
+ * from seam_conv2d_f32's by the order of the fp32 accumulation only. */
+int seam_conv1x1_pc_supported(long long M, int C, int K);
+long long seam_conv1x1_pc_weight_floats(int K, int C);
+int seam_pack_conv1x1_pc_f32(const float* w, float* w_packed, int K, int C, seam_stream_t stream);
+int seam_conv1x1_pc_f32(const float* x, const float* w_packed, const float* scale, const float* shift, const float* residual,
+                        float* y, long long M, int C, int K, int relu, seam_stream_t stream);
+
 /* fp16 twin of seam_conv2d_dual_f32 (x1, x2, w_packed, y fp16; C1 and C2 multiples of 64; fp32 accumulation and epilogue). */
 int seam_conv2d_dual_f16(const void* x1, const void* x2, const void* w_packed, const float* scale,
                          const float* shift, void* y, int N, int Ho, int Wo, int C1, int H2, int W2, int C2,

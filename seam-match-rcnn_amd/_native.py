@@ -46,6 +46,10 @@ SIGNATURES = {
     "seam_preprocess_s2d_batch_f32": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_s2d_batch_f16": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_conv1x1_pc_supported": (_i, [C.c_longlong, _i, _i]),
+    "seam_conv1x1_pc_weight_floats": (C.c_longlong, [_i, _i]),
+    "seam_pack_conv1x1_pc_f32": (_i, [_p, _p, _i, _i, _p]),
+    "seam_conv1x1_pc_f32": (_i, [_p, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i, _p]),
     "seam_conv1x1_sw_config": (_i, [_i, _i, _i, _i]),
     "seam_conv1x1_sw_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -62,6 +62,7 @@ class PackedConv:
     wn: Optional[torch.Tensor] = None   # fp32 1x1 layers with <= 16 outputs: register-resident weights of seam_linear_narrow_f32
     ws: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C <= 256: row-major [K, C] weights (scale folded) of seam_conv1x1_sw_f32
     shift_sw: Optional[torch.Tensor] = None   # ... and its shift vector (zeros when the layer has none)
+    wq: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C >= 256 (a multiple of 128), K % 128 == 0: fragment-order weights of seam_conv1x1_pc_f32
     wh: Optional[torch.Tensor] = None   # fp16 stride-1 3x3 layers (C, K multiples of 128): fragment-order weights of seam_conv3x3_f16pc
 
 
@@ -75,6 +76,10 @@ WINOGRAD = _os.environ.get("SEAM_WINOGRAD", "1") != "0"
 # fp16 path: the stride-1 3x3 layers with C, K multiples of 128 through the producer / consumer kernel (csrc/seam_f16pc.hip);
 # SEAM_F16PC=0 keeps them on the implicit GEMM
 F16PC = _os.environ.get("SEAM_F16PC", "1") != "0"
+# exact-fp32 path: the long-reduction 1x1 layers (C >= 256, a multiple of 128; K a multiple of 128) through the producer / consumer
+# pointwise kernel (csrc/seam_pwpc.hip); SEAM_PWPC=0 keeps them on the implicit GEMM.  Layers the weights-stationary kernel takes
+# (C <= 256) stay there.
+PWPC = _os.environ.get("SEAM_PWPC", "1") != "0"
 F16PC_RULE = True      # dispatch by seam_conv3x3_f16pc_pays (False: every supported shape -- tests, tools/f16pc_ab.py)
 
 
@@ -135,6 +140,11 @@ def _wino_pays(lib, n, h, w, c, k, pad) -> bool:
 # depends on the batch it rides in (the two kernels round differently: folded scale, different k order).
 SW = _os.environ.get("SEAM_PW", "1") != "0"
 SW_MIN_HW = int(_os.environ.get("SEAM_PW_MIN_HW", "196"))
+
+
+# maps of >= 50 x 50 pixels (a function of the map alone, like SW_MIN_HW: an image's result never depends on the batch it rides in): on
+# the 25 x 25 maps a step's 80 frames are 3-6 tiles per CU and the kernel is level with the implicit GEMM (profiles/r05_pwpc_ab.txt)
+PWPC_MIN_HW = int(_os.environ.get("SEAM_PWPC_MIN_HW", "2500"))
 
 
 def _sw_ok(pc: "PackedConv", h: int, w: int) -> bool:
@@ -232,7 +242,13 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         wm = (weight.permute(2, 3, 1, 0).reshape(K, cin) if transposed2x2 else weight.reshape(K, cin)).to(F32)
         ws = (wm * scale[:, None] if scale is not None else wm).contiguous()
         shift_sw = shift if shift is not None else torch.zeros((K,), dtype=F32, device=weight.device)
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw, wh)
+    wq = None
+    if (PWPC and dtype == F32 and mode == 0 and R == 1 and S == 1 and stride == 1 and pad == 0 and cs == cin and ws is None
+            and lib.seam_conv1x1_pc_supported(1 << 20, cs, K)):
+        wq = torch.empty((int(lib.seam_conv1x1_pc_weight_floats(K, cs)),), dtype=F32, device=weight.device)
+        _native.check(lib.seam_pack_conv1x1_pc_f32(_ptr(weight.reshape(K, cin).to(F32).contiguous()), _ptr(wq), K, cs, _stream()),
+                      "seam_pack_conv1x1_pc_f32")
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw, wq, wh)
 
 
 def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -> PackedConv:
@@ -416,6 +432,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     wino = pc.dtype == F32 and pc.u is not None and WINOGRAD and out_hw is None and _wino_pays(lib, n, h, w, c, pc.K, pc.pad)
     wino24 = wino and pc.u24 is not None and WINOGRAD24 and _wino24_pays(lib, n, h, w, c, pc.K, pc.pad)
     sw = not narrow and pc.dtype == F32 and out_hw is None and _sw_ok(pc, h, w)
+    pwpc = (not narrow and not sw and pc.dtype == F32 and pc.wq is not None and PWPC and out_hw is None and h * w >= PWPC_MIN_HW
+            and lib.seam_conv1x1_pc_supported(n * h * w, c, pc.K) == 1)
     f16pc = (pc.dtype == F16 and pc.wh is not None and F16PC and residual is None and out_hw is None and not out_f32 and relu in (0, 1, False, True)
              and (lib.seam_conv3x3_f16pc_pays if F16PC_RULE else lib.seam_conv3x3_f16pc_supported)(n, h, w, c, pc.K, pc.pad) == 1)
     if narrow:
@@ -423,6 +441,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
                       "seam_linear_narrow_f32")
     elif sw:
         _sw_launch(lib, x, None, pc, residual, y, n * h * w, c, 0, relu, 1 if residual is not None else 0)
+    elif pwpc:
+        _native.check(lib.seam_conv1x1_pc_f32(_ptr(x), _ptr(pc.wq), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
+                                              n * h * w, c, pc.K, int(relu), _stream()), "seam_conv1x1_pc_f32")
     elif wino24:
         _native.check(lib.seam_conv3x3_wino24_f32(_ptr(x), _ptr(pc.u24), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                                   n, h, w, c, pc.K, pc.pad, int(relu), _stream()), "seam_conv3x3_wino24_f32")
@@ -455,6 +476,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
             variant = "linear_narrow"
         elif sw:
             variant = _sw_variant(lib, n * h * w, c, pc.K)
+        elif pwpc:
+            variant = "conv1x1_pc"
         elif wino24:
             variant = ("conv3x3_wino24pc" if lib.seam_wino24_form(n, h, w, c, pc.K, pc.pad) == 1
                        else f"conv3x3_wino24<{lib.seam_wino24_variant(n, h, w, c, pc.K, pc.pad)}>")

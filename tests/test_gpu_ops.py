@@ -743,3 +743,52 @@ def test_pointwise_weights_stationary_kernel(ops, shape):
             assert float((got - other).abs().max()) <= 2e-5 * float(other.abs().max()), name
     finally:
         ops.SW = saved
+
+
+@pytest.mark.parametrize("case", [
+    # n, C, H, W, K, relu, bn, residual                (M = n H W: ragged against the 128-pixel tile, one case below it)
+    (2, 512, 25, 25, 2048, True, True, True), (1, 1024, 50, 37, 256, True, True, False), (3, 2048, 13, 11, 512, False, False, False),
+    (2, 512, 41, 29, 128, True, False, True), (1, 384, 9, 9, 256, False, True, False), (1, 256 + 128, 64, 40, 640, True, True, True),
+])
+def test_pointwise_pc_kernel(ops, case):
+    """seam_conv1x1_pc_f32 (producer / consumer pointwise kernel, long reductions) == torch's fp32 convolution at the
+    tolerance of the other exact-fp32 kernels, == the implicit GEMM to summation-order noise, the same bits from launch to launch,
+    and the same bits for an image alone as inside a batch (an output is one wave's fixed fma chain)."""
+    d = dev()
+    n, c, h, w, k, relu, use_bn, use_res = case
+    x = rnd(300, (n, c, h, w))
+    wgt = rnd(301, (k, c, 1, 1), "w") / (c ** 0.5)
+    res = rnd(302, (n, k, h, w)) if use_res else None
+    if use_bn:
+        bn = (torch.from_numpy(synth.uniform(synth.stream_id(303, "bw"), (k,), 0.5, 1.5)), rnd(304, (k,), "bb") * 0.1,
+              rnd(305, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(306, "rv"), (k,), 0.5, 1.5)))
+        pc = ops.pack_conv(wgt.to(d), None, tuple(t.to(d) for t in bn))
+        sc = bn[0] * (bn[3] + 1e-5).rsqrt()
+        ref = F.conv2d(x, wgt) * sc[None, :, None, None] + (bn[1] - bn[2] * sc)[None, :, None, None]
+    else:
+        b = rnd(303, (k,), "b")
+        pc = ops.pack_conv(wgt.to(d), b.to(d))
+        ref = F.conv2d(x, wgt, b)
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    assert pc.wq is not None and pc.ws is None
+    xd = nhwc(x).to(d)
+    rd = nhwc(res).to(d) if use_res else None
+    saved, ops.CONV_TRACE = (ops.PWPC, ops.CONV_TRACE, ops.PWPC_MIN_HW), []
+    try:
+        ops.PWPC, ops.PWPC_MIN_HW = True, 64
+        got = ops.conv2d(xd, pc, relu=relu, residual=rd)
+        assert [t[0] for t in ops.CONV_TRACE] == ["conv1x1_pc"]
+        ops.CONV_TRACE = None
+        assert_close(got.permute(0, 3, 1, 2), ref)
+        for _ in range(20):
+            assert torch.equal(ops.conv2d(xd, pc, relu=relu, residual=rd), got)
+        one = ops.conv2d(xd[n - 1:], pc, relu=relu, residual=None if rd is None else rd[n - 1:])
+        assert torch.equal(one[0], got[n - 1])
+        ops.PWPC = False
+        ig = ops.conv2d(xd, pc, relu=relu, residual=rd)
+        assert float((ig - got).abs().max()) <= 2e-5 * float(ref.abs().max())
+    finally:
+        ops.PWPC, ops.CONV_TRACE, ops.PWPC_MIN_HW = saved

@@ -28,6 +28,10 @@ for i in range($i):
             a = agg[r["Counter_Name"]][key]
             a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             continue
+        if "conv1x1_pc" in r["Kernel_Name"]:
+            a = agg[r["Counter_Name"]]["conv1x1_pc"]
+            a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            continue
         if "conv3x3_f16pc" in r["Kernel_Name"]:
             a = agg[r["Counter_Name"]]["conv3x3_f16pc"]
             a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
