@@ -59,6 +59,9 @@ constexpr int BS = 3;                       // the chunk's barrier follows the M
 constexpr int RB = 8;                       // B fragments in flight per consumer wave: one chunk (8 steps of 8 k) ahead
 constexpr unsigned kOob = 0x80000000u;
 
+#ifndef SEAM_PWPC_ABL
+#define SEAM_PWPC_ABL 0     // experiments: 1 producers idle (no loads / LDS stores), 2 no in-loop A fragment reads, 4 no in-loop B fragment loads
+#endif
 #define LDSQ __attribute__((address_space(3)))
 #define PWPC_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define SB() __builtin_amdgcn_sched_barrier(0)
@@ -164,8 +167,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pc(const PwpcArgs p) {
             PW_TR(11);
             PWPC_BAR();
             PW_TR(12);
+#if !(SEAM_PWPC_ABL & 1)
             if (c + 2 < total_chunks) store_chunk(rq[PAR], buf_c);
             request(rq[PAR]);
+#endif
         };
         for (int c = 0; c < total_chunks; c += 6) {        // (an even number of chunks per tile: the six phases of (c & 1, c % 3))
             step(c, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
@@ -266,13 +271,17 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pc(const PwpcArgs p) {
                                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[st % RB][j], af[m][j], acc[m], 0, 0, 0);
                             }
                             SB();
+#if !(SEAM_PWPC_ABL & 2)
                             if (j == 3) af[m] = read_a(m, st + 1);          // (the next step's fragment: needed four MFMAs = 256 cycles on)
+#endif
                         }
                     }
                     SB();
                     // (no request past the tile's end: a dead load into a ring register would make every epilogue instruction that
                     // reuses the register wait -- in vmcnt order -- for the epilogue's own earlier stores)
+#if !(SEAM_PWPC_ABL & 4)
                     if (t * 8 + st + RB < nsteps) load_b(st % RB, t * 8 + st + RB);
+#endif
                     if (st == BS) {             // B_c: the next chunk is in LDS, the previous one's buffer is free (see the producers)
                         SB();
                         PW_TR(2);
