@@ -178,10 +178,12 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
             pass of the heads (autograd.py) packs per step and keeps the bit-exact fp32 fma chain of the implicit GEMM."""
     lib = _native.lib()
     weight = _req(weight.detach(), name="weight")
+    is_linear = False
     if transposed2x2:
         cin, cout = weight.shape[0], weight.shape[1]
         K, R, S, mode = 4 * cout, 1, 1, 1
     else:
+        is_linear = weight.dim() == 2      # a Linear runs on 1x1 maps: no weight form of the map-sized pointwise kernels
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
         if weight.dim() == 3:
@@ -243,7 +245,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         ws = (wm * scale[:, None] if scale is not None else wm).contiguous()
         shift_sw = shift if shift is not None else torch.zeros((K,), dtype=F32, device=weight.device)
     wq = None
-    if (PWPC and dtype == F32 and mode == 0 and R == 1 and S == 1 and stride == 1 and pad == 0 and cs == cin and ws is None
+    if (PWPC and dtype == F32 and mode == 0 and not is_linear and R == 1 and S == 1 and stride == 1 and pad == 0 and cs == cin and ws is None
             and lib.seam_conv1x1_pc_supported(1 << 20, cs, K)):
         wq = torch.empty((int(lib.seam_conv1x1_pc_weight_floats(K, cs)),), dtype=F32, device=weight.device)
         _native.check(lib.seam_pack_conv1x1_pc_f32(_ptr(weight.reshape(K, cin).to(F32).contiguous()), _ptr(wq), K, cs, _stream()),
