@@ -58,6 +58,19 @@ def test_host_helpers_no_gpu(native):
     assert lib.seam_wino24_form(80, 200, 200, 64, 64, 1) == 1 and lib.seam_wino24_form(80, 13, 13, 256, 256, 1) == 0
     assert lib.seam_wino24_form(80, 200, 200, 32, 64, 1) == 0 and lib.seam_wino24_form(80, 200, 200, 64, 32, 1) == 0
     assert lib.seam_wino24_form(2, 20, 20, 256, 256, 1) == 0 and lib.seam_wino24_form(1, 8, 8, 7, 32, 1) == -1
+    # the producer / consumer pointwise kernel (round 5): long reductions (C >= 256 in pairs of 64-channel chunks), 128-channel output tiles
+    pc = lib.seam_conv1x1_pc_supported
+    assert pc(800000, 512, 256) == 1 and pc(1, 1024, 128) == 1 and pc(200000, 2048, 512) == 1 and pc(50000, 384, 2048) == 1
+    assert pc(800000, 128, 256) == 0 and pc(800000, 320, 256) == 0 and pc(800000, 512, 192) == 0 and pc(0, 512, 256) == 0
+    assert lib.seam_conv1x1_pc_weight_floats(256, 512) == 256 * 512
+    # the fp16 producer / consumer 3x3 kernel: shapes it takes, and the dispatch rule (tiles >= 3/4 full, a function of the map only)
+    sup, pays = lib.seam_conv3x3_f16pc_supported, lib.seam_conv3x3_f16pc_pays
+    assert sup(48, 192, 336, 256, 256, 1) == 1 and sup(1536, 14, 14, 256, 256, 1) == 1 and sup(1536, 8, 8, 256, 1024, 0) == 1
+    assert sup(48, 192, 336, 64, 64, 1) == 0 and sup(48, 192, 336, 256, 192, 1) == 0 and sup(48, 20, 20, 256, 256, 1) == 0
+    assert sup(48, 192, 336, 256, 256, 2) == 0 and sup(4, 2, 2, 256, 256, 0) == 0
+    assert pays(48, 192, 336, 256, 256, 1) == 1 and pays(1, 192, 336, 256, 256, 1) == 1 and pays(1536, 14, 14, 256, 256, 0) == 1
+    assert pays(48, 24, 42, 512, 512, 1) == 0 and pays(48, 192, 336, 64, 64, 1) == 0
+    assert lib.seam_f16pc_weight_halves(256, 256) == 256 * 256 * 9
 
 
 def test_product_path_fails_loudly_without_gpu(native):
