@@ -32,6 +32,16 @@ int seam_version(void);
 /* hipGetErrorString for a code returned by any entry point. */
 const char* seam_error_string(int code);
 
+/* Variant selectors of the launchers (kernel-form switches the parity tests and the A/B tools flip: which Winograd form,
+ * persistent or one tile per block, a forced implicit-GEMM tile ...).  A launcher never reads the environment; these are
+ * process-wide ints, named like the environment variables the Python host applies once at load time ("SEAM_W24_PC", ...;
+ * the table is csrc/seam_opts.h).  Every variant of a kernel computes the same results (bit-identical where the tests say so).
+ * seam_set_option / seam_get_option return 0, or hipErrorInvalidValue for an unknown name. */
+int seam_option_count(void);
+const char* seam_option_name(int index);           /* NULL outside [0, count) */
+int seam_set_option(const char* name, int value);
+int seam_get_option(const char* name, int* value);
+
 /* ---------------------------------------------------------------------------------
  * Implicit-GEMM convolution, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * Replaces every conv / linear on the path:

@@ -31,6 +31,10 @@ class TrunkLayer(C.Structure):
 SIGNATURES = {
     "seam_version": (_i, []),
     "seam_error_string": (C.c_char_p, [_i]),
+    "seam_option_count": (_i, []),
+    "seam_option_name": (C.c_char_p, [_i]),
+    "seam_set_option": (_i, [C.c_char_p, _i]),
+    "seam_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
     "seam_conv_kred": (_i, [_i, _i, _i]),
     "seam_conv_rows_padded": (_i, [_i]),
     "seam_conv_tile": (_i, [_i, _i]),
@@ -167,8 +171,38 @@ def lib() -> C.CDLL:
             raise SeamNativeError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    _apply_env_options(handle)
     _lib = handle
     return _lib
+
+
+def _apply_env_options(handle) -> None:
+    """The launchers' variant selectors (csrc/seam_opts.h) are plain ints behind ``seam_set_option``: the library itself never
+    reads the environment.  For the parity tests and the A/B tools, SEAM_* environment variables of the same names are applied
+    here, once, when the library is loaded (``SEAM_CONV_TILE=256x128`` is passed as 256128)."""
+    for i in range(handle.seam_option_count()):
+        name = handle.seam_option_name(i)
+        raw = os.environ.get(name.decode())
+        if raw is None or raw == "":
+            continue
+        if "x" in raw:
+            bm, bn = raw.split("x")
+            val = int(bm) * 1000 + int(bn)
+        else:
+            val = int(raw)
+        check_rc = handle.seam_set_option(name, val)
+        if check_rc != 0:
+            raise SeamNativeError(f"seam_set_option({name!r}, {val}) failed: {check_rc}")
+
+
+def set_option(name: str, value: int) -> None:
+    check(lib().seam_set_option(name.encode(), int(value)), f"seam_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib().seam_get_option(name.encode(), C.byref(v)), f"seam_get_option({name})")
+    return v.value
 
 
 def check(code: int, what: str) -> None:

@@ -30,6 +30,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include "seam_opts.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -967,10 +968,10 @@ inline int tile_weight(int prec, int bm, int bn, int taps) {
 inline void choose_tile(int prec, int M, int K, int& best_bm, int& best_bn, int taps = 1) {
     const int rows = ((K + 63) / 64) * 64;
     const int slab = rows % 128 == 0 ? 128 : 64;
-    static const char* force = getenv("SEAM_CONV_TILE");           // kernel experiments: "256x128", "128x128", ...
+    const int force = seam_opt::get(seam_opt::CONV_TILE);           // kernel experiments: BM * 1000 + BN (256128, 128128, ...)
     if (force) {
-        int fm = 0, fn = 0;
-        if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 256 || fm == 128 || fm == 64) && (fn == 128 || fn == 64) &&
+        const int fm = force / 1000, fn = force % 1000;
+        if ((fm == 256 || fm == 128 || fm == 64) && (fn == 128 || fn == 64) &&
             fn <= slab && (fm != 256 || fn == 128)) {
             best_bm = fm; best_bn = fn;
             return;
@@ -1020,10 +1021,8 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.M = N * a.Ho * a.Wo;
     a.relu = relu;
     a.y_f32 = y_f32;
-    static const int vec_epi = getenv("SEAM_F16_VEC_EPILOGUE") ? atoi(getenv("SEAM_F16_VEC_EPILOGUE")) : 1;
-    a.vec_epi = vec_epi;
-    static const int epi_prio = getenv("SEAM_EPI_PRIO") ? atoi(getenv("SEAM_EPI_PRIO")) : 1;
-    a.epi_prio = epi_prio;
+    a.vec_epi = seam_opt::get(seam_opt::F16_VEC_EPILOGUE);
+    a.epi_prio = seam_opt::get(seam_opt::EPI_PRIO);
 
     a.rH = rH; a.rW = rW;
     a.x2 = nullptr; a.H2 = a.W2 = a.C2 = a.stride2 = 0;
@@ -1045,11 +1044,11 @@ int conv2d(const void* x, const void* w_packed, const float* scale, const float*
     a.tiles_n = rows / best_bn;
     // persistent blocks: one per resident slot (256 CUs x 2 blocks of 4 waves, or x 1 block of 8 waves); a multiple of 8 so
     // that a block's tiles stay on its XCD
-    static const int slots4 = getenv("SEAM_CONV_SLOTS") ? atoi(getenv("SEAM_CONV_SLOTS")) : 512;      // dev knob
+    const int slots4 = seam_opt::get(seam_opt::CONV_SLOTS);      // dev knob
     const int ntiles = a.tiles_m * a.tiles_n;
     const int slots = best_bm == 256 ? slots4 / 2 : slots4;
     const dim3 grid(ntiles < slots ? ntiles : slots);
-    static const int dyn = getenv("SEAM_CONV_DYNLDS") ? atoi(getenv("SEAM_CONV_DYNLDS")) : 0;   // dev knob: occupancy experiments
+    const int dyn = seam_opt::get(seam_opt::CONV_DYNLDS);   // dev knob: occupancy experiments
     hipStream_t st = (hipStream_t)stream;
     {
         if (dual) {

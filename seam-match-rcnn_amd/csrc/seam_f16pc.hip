@@ -32,7 +32,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
-#include <stdio.h>
+#include "seam_opts.h"
+#if defined(SEAM_F16PC_TRACE)
+#include "dev/seam_trace_host.h"      // -DSEAM_DEV_BUILD experiment builds only (tools/experiments/f16pc_abl.sh)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -516,27 +519,10 @@ int f16pc_launch(const F16Args& a, hipStream_t st) {
     const int ncu = cus[dev & 31].load(std::memory_order_relaxed);
     const unsigned grid = (unsigned)(a.total_tiles > ncu ? ncu : a.total_tiles);
 #ifdef SEAM_F16PC_TRACE
-    static unsigned long long* tbuf = nullptr;
-    if (!tbuf) (void)hipMalloc((void**)&tbuf, 8 * 2048 * 8);
-    (void)hipMemset(tbuf, 0, 8 * 2048 * 8);
-    F16Args b = a; b.trace = tbuf;
+    static seam_dev::TraceBuf tb;
+    F16Args b = a; b.trace = seam_dev::trace_begin(tb, 8 * 2048);
     hipLaunchKernelGGL(conv3x3_f16pc<PWI>, dim3(grid), dim3(512), LDS_BYTES, st, b);
-    {
-        static int dumped = 0;
-        (void)hipDeviceSynchronize();
-        if (dumped++ == 2) {
-            static unsigned long long h[8 * 2048];
-            (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
-            for (int w = 0; w < 8; w += 4) {
-                unsigned long long prev = 0;
-                for (int k = 0; k < 2048 && h[w * 2048 + k]; ++k) {
-                    const unsigned long long v = h[w * 2048 + k], tm = v & 0x00ffffffffffffffull;
-                    fprintf(stderr, "TR wave %d k %d tag %d d %lld\n", w, k, (int)(v >> 56), prev ? (long long)(tm - prev) : 0ll);
-                    prev = tm;
-                }
-            }
-        }
-    }
+    seam_dev::trace_end(tb, 2, 2048, false, 0);
     return (int)hipGetLastError();
 #else
     hipLaunchKernelGGL(conv3x3_f16pc<PWI>, dim3(grid), dim3(512), LDS_BYTES, st, a);

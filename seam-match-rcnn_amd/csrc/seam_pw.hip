@@ -28,6 +28,7 @@
 #include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
+#include "seam_opts.h"
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -324,7 +325,7 @@ int seam_conv1x1_sw_f32(const float* x, const float* x2, const float* w, const f
     const size_t lds = (size_t)(32 * NT) * (Ct * 4 + 16) + PW_WAVES * TBUF;
     // one block per CU; fewer when the rows do not fill them (a block's first act is to copy its slab): blocks per slab = row
     // tiles / 8 waves, rounded up to the 8 XCDs.  The grid never changes a result (each output pixel is one wave's fixed fma chain).
-    static const int max_blk = getenv("SEAM_PW_BLOCKS") ? atoi(getenv("SEAM_PW_BLOCKS")) : 256;      // dev knob; a multiple of 64
+    const int max_blk = seam_opt::get(seam_opt::PW_BLOCKS);      // dev knob; a multiple of 64
     if (max_blk < 64 || max_blk % 64 || max_blk < 8 * a.ns) return (int)hipErrorInvalidValue;
     const int tiles = (M + 32 * MT - 1) / (32 * MT);
     int per_slab = (((tiles + PW_WAVES - 1) / PW_WAVES + 7) / 8) * 8;

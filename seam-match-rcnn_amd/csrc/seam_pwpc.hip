@@ -35,7 +35,10 @@
 #include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
-#include <stdio.h>
+#include "seam_opts.h"
+#if defined(SEAM_PWPC_TRACE)
+#include "dev/seam_trace_host.h"      // -DSEAM_DEV_BUILD experiment builds only (tools/experiments/pwpc_abl.sh)
+#endif
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -244,7 +247,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pc(const PwpcArgs p) {
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            rv[m][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ocol, m * K32 + i * K8, 0));
+                            // (the row step rides in the VECTOR offset: the descriptor's range check covers vector offset + immediate only, a
+                            //  scalar offset is added unchecked -- on a ragged last tile the rows past `rows` must fall outside and read zero)
+                            rv[m][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ocol + m * K32 + i * K8, 0, 0));
                 }
                 const int nbuf = cbuf == NBUF - 1 ? 0 : cbuf + 1;
                 const LDSQ char* const ac = ab + cbuf * ABUF;
@@ -411,27 +416,10 @@ int seam_conv1x1_pc_f32(const float* x, const float* w_packed, const float* scal
     const int ncu = cus[dev & 31].load(std::memory_order_relaxed);
     const unsigned grid = (unsigned)(a.total_tiles > ncu ? ncu : a.total_tiles);
 #ifdef SEAM_PWPC_TRACE
-    static unsigned long long* tbuf = nullptr;
-    if (!tbuf) (void)hipMalloc((void**)&tbuf, 8 * 1024 * 8);
-    (void)hipMemset(tbuf, 0, 8 * 1024 * 8);
-    a.trace = tbuf;
+    static seam_dev::TraceBuf tb;
+    a.trace = seam_dev::trace_begin(tb, 8 * 1024);
     hipLaunchKernelGGL(conv1x1_pc, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
-    {
-        static int dumped = 0;
-        (void)hipDeviceSynchronize();
-        if (dumped++ == 2) {
-            static unsigned long long h[8 * 1024];
-            (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
-            for (int w = 0; w < 8; w += 4) {
-                unsigned long long prev = 0;
-                for (int k = 0; k < 1024 && h[w * 1024 + k]; ++k) {
-                    const unsigned long long v = h[w * 1024 + k], tm = v & 0x00ffffffffffffffull;
-                    fprintf(stderr, "TR wave %d k %d tag %d d %lld\n", w, k, (int)(v >> 56), prev ? (long long)(tm - prev) : 0ll);
-                    prev = tm;
-                }
-            }
-        }
-    }
+    seam_dev::trace_end(tb, 2, 1024, false, 0);
     return (int)hipGetLastError();
 #else
     a.trace = nullptr;

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "seam_opts.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -387,11 +388,10 @@ __global__ __launch_bounds__(256) void roi_align_quad_kernel(const RoiArgs p) {
     }
 }
 
-int g_roi_lds = -1;              // -1: read SEAM_ROIALIGN_LDS on first use: 0 gather, 1 row-staged tiles, 2 (default) quadrant tiles -- profiles/r03_roialign_ab.txt
 
 }  // namespace
 
-extern "C" void seam_roi_align_set_lds(int on) { g_roi_lds = on < 0 ? 0 : on > 2 ? 2 : on; }
+extern "C" void seam_roi_align_set_lds(int on) { seam_opt::g_value[seam_opt::ROIALIGN_LDS].store(on < 0 ? 0 : on > 2 ? 2 : on, std::memory_order_relaxed); }
 
 template <typename T>
 static int roi_align_launch(const void* feat0, const void* feat1, const void* feat2, const void* feat3, const int* hw, int C,
@@ -405,10 +405,7 @@ static int roi_align_launch(const void* feat0, const void* feat1, const void* fe
     a.scale[0] = scale0; a.scale[1] = scale1; a.scale[2] = scale2; a.scale[3] = scale3;
     a.C = C; a.k_min = k_min; a.rois = rois; a.levels = levels; a.out = out; a.K = K; a.P = P;
     a.sr = sampling_ratio;
-    if (g_roi_lds < 0) {
-        const char* e = getenv("SEAM_ROIALIGN_LDS");
-        g_roi_lds = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : 2;
-    }
+    const int g_roi_lds = seam_opt::get(seam_opt::ROIALIGN_LDS);      // 0 gather, 1 row-staged tiles, 2 (default) quadrant tiles
     if (g_roi_lds == 2 && sampling_ratio == 2 && P <= 16 && (C % RA_CB) == 0) {
         // (64 channels per block; 32 -- more blocks per CU -- measured 2.2x slower in fp32: 128-byte pixel rows alias in LDS)
         hipLaunchKernelGGL((roi_align_quad_kernel<T, RA_CB>), dim3((unsigned)((long)K * (C / RA_CB) * 4)), dim3(256), 0, (hipStream_t)stream, a);

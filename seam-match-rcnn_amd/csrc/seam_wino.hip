@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "seam_opts.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -613,7 +614,7 @@ static int wino_plan(WinoArgs& a, int N, int H, int W, int C, int K, int pad, in
     if (a.Ho <= 0 || a.Wo <= 0) return (int)hipErrorInvalidValue;
     if ((size_t)H * W * C * 4 >= kOob || (size_t)a.Ho * a.Wo * K * 4 >= kOob) return (int)hipErrorInvalidValue;
     const int tiles_x = (a.Wo + 1) / 2, tiles_y = (a.Ho + 1) / 2;
-    static const int force_mt = getenv("SEAM_WINO_MT") ? atoi(getenv("SEAM_WINO_MT")) : 0;    // kernel experiments
+    const int force_mt = seam_opt::get(seam_opt::WINO_MT);    // kernel experiments
     const size_t in_b = (size_t)H * W * C * 4, out_b = (size_t)a.Ho * a.Wo * K * 4;
     const Layout p2 = choose_layout(N, tiles_x, tiles_y, 2, in_b, out_b), p1 = choose_layout(N, tiles_x, tiles_y, 1, in_b, out_b);
     a.tiles_n = K / 32;

@@ -27,7 +27,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <stdio.h>
+#include "seam_opts.h"
+#if defined(SEAM_W24PC_TRACE)
+#include "dev/seam_trace_host.h"      // -DSEAM_DEV_BUILD experiment builds only (tools/experiments/w24pc_abl.sh)
+#endif
 #include <atomic>
 #include <type_traits>
 
@@ -258,9 +261,10 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     constexpr int NRS = NT == 1 ? 2 : 1;     // register sets of the raw patch: prefetch distance 2 chunks / 1 (twice as long) chunk
     f32x4 rset[NRS][NI];
     auto load_raw = [&](f32x4 (&rs)[NI], int chunk) {
-        // chunks past the end (the prefetch runs 2-4 ahead) are not clamped: they read the next pixel's channels or fall outside
-        // the descriptor (zero fill) and are never used -- one scalar shift per chunk instead of a compare/select per load group
-        const int so = chunk * 32;
+        // chunks past the end (the prefetch runs 2-4 ahead) re-read the last chunk and are never used.  (Clamped, one s_min: the
+        // chunk offset rides in the SCALAR offset, which the descriptor's range check does not cover -- unclamped, the last
+        // pixel of the image group would read up to 128 bytes past x.)
+        const int so = min(chunk, p.nchunks - 1) * 32;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
             rs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[i], so, 0));
@@ -275,15 +279,15 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.u + (size_t)tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
     // lane offsets of positions nu = 0..3 and 4..5: the per-position 1 KiB steps then fit the instruction's 12-bit immediate, and the
-    // scalar offset is one value per chunk (and n-tile).  Chunks past the end are not clamped: they read the next n-tile's first
-    // chunk or fall outside the descriptor (zero fill), and are never used.
+    // scalar offset is one value per chunk (and n-tile).  Chunks past the end are clamped to the last one (the scalar offset is not
+    // range-checked by the descriptor: unclamped, the last n-tile would read one chunk past the packed weights) and never used.
     // (ONE lane offset, made opaque once per chunk: hipcc otherwise hoists the six "offset + nu KiB" sums out of the K loop, parks
     //  them in AccVGPRs and pays a v_accvgpr_read -- a vector-ALU instruction, i.e. ~20 idle cycles of the fp32 matrix pipe -- per load)
     int uoff0 = (xi * 6 * 64 + lane) * 16;
     constexpr int NBS = 2;                   // weight register sets: chunk t + 1's are requested at the top of chunk t
     f32x4 bfs[NBS][NT][6];
     auto load_b = [&](f32x4 (&bf)[NT][6], int nu, int chunk) {       // position nu of every n-tile
-        const int so = chunk * 24576 + (nu >> 2) * 4096;
+        const int so = min(chunk, p.nchunks - 1) * 24576 + (nu >> 2) * 4096;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             bf[nt][nu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff0 + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
@@ -883,9 +887,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         //  region of a non-stacked map: their patch has the same shape, so each piece's patch coordinates (kept packed in `vp`)
         //  and LDS address are unchanged and only the image offset and the border tests are redone -- ~150 instructions.)
         int vp[NP];                             // piece r's patch row | column << 16 in the region `vp_reg` (row 0x7fff: no pixel)
-        int vp_reg = -1;                        // -1: nothing cached (stacked maps: the image wrap differs from tile to tile)
+        int vp_reg = -1;                        // -1: nothing cached
         auto setup_patch = [&](const PcGeo& q, LDSQ char* (&lp_)[NP]) {
-            if (!p.stack && q.reg == vp_reg) {
+            const int pitch = 2 * p.tiles_y + 2;
+            if (q.reg == vp_reg) {
+                if (p.stack) {
+                    // stacked maps (round 6): the patch shape is the same for every tile, only the row at which the images wrap moves
+                    // (prow0) -- the piece's patch coordinates and LDS address stay, the image index and its row are redone
+#pragma unroll
+                    for (int r = 0; r < NP; ++r) {
+                        const int v = vp[r] & 0xffff, px = vp[r] >> 16;
+                        const int vr = q.prow0 + v;                 // v = 0x7fff (no pixel): an image index far outside the group
+                        const int g = fdiv(vr, pitch, p.m_pitch);
+                        const int gy = vr - __mul24(g, pitch) - p.pad, gx = q.ix0 + px;
+                        const bool inb = g < q.n_here && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                        goff[r] = inb ? (unsigned)((__mul24(__mul24(__mul24(g, p.H) + gy, p.W) + gx, p.C) + (ptid & 7) * 4) * 4) : kOob;
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int r = 0; r < NP; ++r) {
                     const int v = vp[r] & 0xffff, px = vp[r] >> 16;
@@ -895,7 +914,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                 }
                 return;                         // lp_ (= lpn): this region's addresses already
             }
-            const int pitch = 2 * p.tiles_y + 2;
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 const int pix = (ptid >> 3) + 32 * r;
@@ -916,7 +934,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                                        : 2 * ENTMAX * 16);
                 vp[r] = pix < q.NPIX ? (v | (px << 16)) : 0x7fff;
             }
-            vp_reg = p.stack ? -1 : q.reg;
+            vp_reg = q.reg;
         };
         auto setup_read = [&](const PcGeo& q) {
             // input transform of row xi: T_j = d[ra][j] + cb * d[rb][j]  (rows: xi0: d0 - d2, xi1: d1 + d2, xi2: d2 - d1, xi3: d1 - d3)
@@ -956,7 +974,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         f32x4 rq[2][NP];                        // the pieces of two groups (group parity)
         f32x4 xa[3], xb[3], ya[3], yb[3], va[6];
         auto load_group = [&](f32x4 (&dst)[NP]) {      // request group gL of the load stage's tile
-            const int so = gL * 128;            // groups past the end: the next pixel's channels or zero fill, never used
+            const int so = min(gL, (n >> 2) - 1) * 128;     // (never past a tile's last group: the scalar offset is not range-checked)
 #pragma unroll
             for (int r = 0; r < NP; ++r)
                 dst[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcL, goff[r], so, 0));
@@ -1152,7 +1170,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         for (int k = 0; k < ntiles; ++k) {
             const PcGeo q = pc_geo(p, tile);
             auto load_b = [&](int slot_, int nu, int chunk) {
-                const int so = chunk * 24576 + (nu >> 2) * 4096;
+                const int so = min(chunk, n - 1) * 24576 + (nu >> 2) * 4096;     // (clamped: the scalar offset is not range-checked)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     bq[slot_][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff0 + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
@@ -1196,8 +1214,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                             SB();
                         }
                     if (!(SEAM_W24PC_ABL & 2)) {
-                        const int j2 = jl + RING;                   // the instance that takes over this slot (chunks past the end:
-                        load_b(sl, j2 % 6, t - c + j2 / 6);         // the next n-tile's data or zero fill, never used)
+                        const int j2 = jl + RING;                   // the instance that takes over this slot (chunks past the end
+                        load_b(sl, j2 % 6, t - c + j2 / 6);         // re-read the last chunk, never used)
                     }
                     SB();
                     if (i == 5 - AD) {          // every fragment of this chunk is in registers (or on its way, waited for by the barrier
@@ -1442,11 +1460,11 @@ inline int wino24_nt(int K, int C, long blocks_nt1) {
     // NT = 2 pays where the K loop is long enough to amortise a block that is alone on its CU (C >= 256) and the launch still fills
     // the chip several times over with half as many blocks (measured per layer shape with tools/w24_ab.py; both forms compute
     // bit-identical results, so the choice may depend on the batch).  SEAM_W24_NT=1|2 forces a form.
-    static const int force = getenv("SEAM_W24_NT") ? atoi(getenv("SEAM_W24_NT")) : 0;
+    const int force = seam_opt::get(seam_opt::W24_NT);
     if (K % 64) return 1;
     if (force == 1 || force == 2) return force;
     // round 5: on the producer / consumer kernel the shorter K loops of the C = 64 / 128 layers pay as well (80 x 100^2 x 128: -6 %)
-    static const int pc = getenv("SEAM_W24_PC") ? atoi(getenv("SEAM_W24_PC")) : 1;
+    const int pc = seam_opt::get(seam_opt::W24_PC);
     const int cmin = pc && C % 64 == 0 ? 64 : 256;
     return (C >= cmin && blocks_nt1 / 2 >= 1024) ? 2 : 1;
 }
@@ -1459,7 +1477,7 @@ inline int wino24_nsplit(int C, int K, long patch_blocks) {
 
 // the producer / consumer kernel takes the NT = 2 launches (SEAM_W24_PC=0: conv3x3_wino24<2>, the round-4 kernel, stays selectable)
 inline bool wino24_pc(const Wino24Args& a) {
-    static const int want = getenv("SEAM_W24_PC") ? atoi(getenv("SEAM_W24_PC")) : 1;
+    const int want = seam_opt::get(seam_opt::W24_PC);
     return want && a.nt == 2 && a.nsplit == 1 && a.nchunks >= 8 && a.nchunks % 8 == 0;
 }
 
@@ -1483,7 +1501,7 @@ int wino24_plan(Wino24Args& a, int N, int H, int W, int C, int K, int pad, long&
     }
     blocks = pp.blocks * a.tiles_n;
     {
-        static const int want = getenv("SEAM_W24_NSPLIT") ? atoi(getenv("SEAM_W24_NSPLIT")) : 0;
+        const int want = seam_opt::get(seam_opt::W24_NSPLIT);
         int ns = want > 0 ? want : wino24_nsplit(C, K, pp.blocks);
         while (ns > 1 && (a.tiles_n % ns || 8 % ns)) ns >>= 1;
         a.nsplit = ns < 1 ? 1 : ns;
@@ -1552,7 +1570,7 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
     a.relu = relu;
     a.trace = nullptr;
     a.total_tiles = 0;
-    static const int dyn = getenv("SEAM_W24_DYNLDS") ? atoi(getenv("SEAM_W24_DYNLDS")) : 0;     // dev knob: occupancy experiments
+    const int dyn = seam_opt::get(seam_opt::W24_DYNLDS);     // dev knob: occupancy experiments
     if (wino24_pc(a)) {
         // > 64 KiB of dynamic LDS needs the attribute once per device (an atomic flag per device: the ABI is thread-safe per stream)
         static std::atomic<unsigned> attr_done{0};
@@ -1569,7 +1587,7 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
             attr_done.fetch_or(bit, std::memory_order_release);
         }
         // persistent grid: one block per CU walks its XCD's tile range (SEAM_W24_PERSIST=0: one tile per block)
-        static const int persist = getenv("SEAM_W24_PERSIST") ? atoi(getenv("SEAM_W24_PERSIST")) : 1;
+        const int persist = seam_opt::get(seam_opt::W24_PERSIST);
         a.total_tiles = (int)blocks;
         for (int r = 0; r < 3; ++r) {
             a.rg[r].TX = a.TX[r]; a.rg[r].TY = a.TY[r]; a.rg[r].bx = a.bx[r]; a.rg[r].by = a.by[r];
@@ -1580,42 +1598,12 @@ int seam_conv3x3_wino24_f32(const float* x, const float* u_packed, const float* 
         const int ncu = cus[dev & 31].load(std::memory_order_relaxed);
         const unsigned grid = (unsigned)(persist && blocks > ncu ? ncu : blocks);
 #ifdef SEAM_W24PC_TRACE
-        static unsigned long long* tbuf = nullptr;
-        if (!tbuf) (void)hipMalloc((void**)&tbuf, (8 * 4096 + 2 * 1024) * 8);
-        (void)hipMemset(tbuf, 0, (8 * 4096 + 2 * 1024) * 8);
-        a.trace = tbuf;
+        static seam_dev::TraceBuf tb;
+        a.trace = seam_dev::trace_begin(tb, 8 * 4096 + 2 * 1024);
 #endif
         hipLaunchKernelGGL(conv3x3_wino24pc<SEAM_W24PC_RING>, dim3(grid), dim3(512), PC_LDS, (hipStream_t)stream, a);
 #ifdef SEAM_W24PC_TRACE
-        {
-            static int dumped = 0;
-            (void)hipDeviceSynchronize();
-            if (dumped++ == 3) {
-                static unsigned long long h[8 * 4096 + 2 * 1024];
-                (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
-                {
-                    unsigned long long mn = ~0ull, mx = 0, sum = 0; int nb = 0;
-                    unsigned long long xs[8] = {0}, xn[8] = {0};
-                    for (unsigned b = 0; b < grid && b < 1024; ++b) {
-                        const unsigned long long v = h[8 * 4096 + 2 * b];
-                        if (!v) continue;
-                        mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; ++nb; xs[b & 7] += v; xn[b & 7]++;
-                    }
-                    fprintf(stderr, "BLOCKSPAN blocks %d min %llu avg %llu max %llu cycles; per XCD avg:", nb, mn, nb ? sum / nb : 0, mx);
-                    for (int x = 0; x < 8; ++x) fprintf(stderr, " %llu", xn[x] ? xs[x] / xn[x] : 0);
-                    fprintf(stderr, "\n");
-                    for (unsigned b = 0; b < grid && b < 1024; b += 37) fprintf(stderr, "BLOCK %u span %llu tiles %llu\n", b, h[8 * 4096 + 2 * b], h[8 * 4096 + 2 * b + 1]);
-                }
-                for (int w = 0; w < 8; w += 4) {
-                    unsigned long long prev = 0;
-                    for (int k = 0; k < 4096 && h[w * 4096 + k]; ++k) {
-                        const unsigned long long v = h[w * 4096 + k], tm = v & 0x00ffffffffffffffull;
-                        fprintf(stderr, "TR wave %d k %d tag %d t %llu d %lld\n", w, k, (int)(v >> 56), tm, prev ? (long long)(tm - prev) : 0ll);
-                        prev = tm;
-                    }
-                }
-            }
-        }
+        seam_dev::trace_end(tb, 3, 4096, true, grid < 1024 ? grid : 1024);
 #endif
         return (int)hipGetLastError();
     }

@@ -1,0 +1,465 @@
+"""Random-shape stress of the hand-scheduled kernels through the C ABI.
+
+``conv3x3_wino24pc`` (persistent producer / consumer Winograd F(2x4,3x3), hand-counted ``vmcnt`` waits, a cross-tile software
+pipeline, cached per-region addresses, 24-bit multiplies guarded by launcher caps), ``conv1x1_pc``, ``conv3x3_f16pc`` and
+``conv1x1_sw`` each get >= 200 seeded random shapes: every launch goes onto a POISONED output, twice, and must be bit-identical;
+results are compared with the implicit GEMM (``seam_conv2d_f32`` / ``_f16``) AND with a plain torch fp32 convolution of the same
+operands (tap-wise ``matmul`` form for every shape -- no per-shape MIOpen search -- and ``F.conv2d`` itself on a sample).
+Unserved channel counts must be REFUSED (non-zero return), not hang.  Shapes cover N in [1, 3000], H, W in [3, 210] including
+primes, pad 0 / 1, every epilogue mode, grids smaller than the CU count (one tile, one tile per XCD), tile ranges that end
+mid-region, and the launcher's 2^31-byte cap from both sides.  (The ``blocks >= 2^24`` cap is hit from the refusing side only:
+a launch just under it needs a 1 TB output.)
+
+The whole sweep runs in ONE child process under a wall-clock timeout, so a kernel that hangs is a test FAILURE that names the
+shape it hung on (the child prints every shape before launching it) -- not a lost GPU lease.  The reference's own layers are
+shape-polymorphic in the same way: ``MatchPredictor.conv_seq`` (/root/reference/models/match_head.py:50-62) runs on whatever ROI
+count arrives.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCASE = 200
+WALL_S = 240          # a hang shows as this timeout; the sweep itself takes well under 90 s
+
+_CHILD = r'''
+import math, random, sys, time
+import torch
+import torch.nn.functional as F
+import seam_match_rcnn_amd.ops as ops
+from seam_match_rcnn_amd import _native
+
+NCASE, SEED = int(sys.argv[1]), int(sys.argv[2])
+dev = torch.device("cuda:0")
+lib = _native.lib()
+st = lambda: torch.cuda.current_stream().cuda_stream
+P = lambda t: None if t is None else t.data_ptr()
+PRIMES = [3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113, 127,
+          131, 137, 139, 149, 151, 157, 163, 167, 173, 179, 181, 191, 193, 197, 199]
+fails = []
+
+
+def say(*a):
+    print(*a, flush=True)
+
+
+def gen(rng):
+    g = torch.Generator(device=dev)
+    g.manual_seed(rng.randrange(1 << 30))
+    return g
+
+
+def dim(rng, lo=3, hi=210):
+    r = rng.random()
+    if r < 0.3:
+        return rng.choice([p for p in PRIMES if lo <= p <= hi])
+    if r < 0.5:
+        return rng.choice([v for v in (6, 8, 10, 12, 14, 16, 25, 50, 100, 200, 210) if lo <= v <= hi])
+    return rng.randint(lo, hi)
+
+
+def pick_n(rng, per_img, budget):
+    nmax = max(1, min(3000, budget // max(per_img, 1)))
+    r = rng.random()
+    if r < 0.25:
+        return rng.randint(1, min(3, nmax))
+    if r < 0.35:
+        return nmax
+    return rng.randint(1, nmax)
+
+
+def epilogue_vectors(rng, k, g):
+    mode = rng.choice(["none", "bias", "bn"])
+    scale = shift = None
+    if mode == "bias":
+        shift = torch.randn(k, device=dev, generator=g) * 0.2
+    elif mode == "bn":
+        scale = torch.rand(k, device=dev, generator=g) + 0.5
+        shift = torch.randn(k, device=dev, generator=g) * 0.2
+    return scale, shift
+
+
+def torch_epilogue(acc, scale, shift, res, relu):
+    y = acc
+    if scale is not None:
+        y = y * scale
+    if shift is not None:
+        y = y + shift
+    if relu == 2:
+        return torch.where(res > 0, y, torch.zeros_like(y))
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu == 1 else y
+
+
+def torch_conv3x3(x, wt, pad):
+    """fp32 3x3 / stride-1 convolution of an NHWC tensor as nine tap-wise matmuls (plain torch, no per-shape algorithm search)."""
+    n, h, w, c = x.shape
+    k = wt.shape[0]
+    xp = F.pad(x, (0, 0, pad, pad, pad, pad)) if pad else x
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    acc = torch.zeros((n * ho * wo, k), dtype=torch.float32, device=x.device)
+    for r in range(3):
+        for s in range(3):
+            acc += xp[:, r:r + ho, s:s + wo, :].reshape(-1, c).float() @ wt[:, :, r, s].float().t()
+    return acc.view(n, ho, wo, k)
+
+
+def check(name, desc, got, got2, refs, tol):
+    ok = True
+    why = ""
+    if not torch.equal(got, got2):
+        ok, why = False, "two launches differ"
+    elif not bool(torch.isfinite(got.float()).all()):
+        ok, why = False, "poison / non-finite values left in the output"
+    else:
+        for rname, ref in refs:
+            sc = max(float(ref.float().abs().max()), 1e-20)
+            err = float((got.float() - ref.float()).abs().max()) / sc
+            if not err <= tol:
+                ok, why = False, f"{err:.2e} of scale from {rname}"
+                break
+    if not ok:
+        fails.append((name, desc, why))
+        say("FAIL", name, desc, why)
+    return ok
+
+
+def poisoned(shape, dtype, which):
+    return torch.full(shape, float("nan") if which == 0 else 3.0e4, dtype=dtype, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------ conv3x3_wino24pc
+def stress_wino24pc(rng):
+    t0 = time.time()
+    done = conv_checked = 0
+    small = xcd1 = mid = 0
+    while done < NCASE:
+        c = rng.choice([64, 64, 128, 192, 256, 256, 320, 512])
+        k = rng.choice([64, 128, 192, 256, 512])
+        pad = rng.randint(0, 1)
+        big = rng.random() < 0.08
+        r = rng.random()
+        if r < 0.35:            # ROI-sized / stacked maps
+            h = rng.choice([3, 4, 5, 6, 7, 8, 10, 12, 13, 14, 16, 17, 20, 25])
+            w = h if rng.random() < 0.6 else rng.choice([3, 5, 6, 8, 10, 12, 14, 16, 19, 25, 31])
+        else:
+            h, w = dim(rng), dim(rng)
+        if h + 2 * pad < 3 or w + 2 * pad < 3:
+            continue
+        budget = (24 if big else 3) << 20
+        n = pick_n(rng, h * w * max(c, k), budget)
+        forced = rng.random() < 0.55
+        _native.set_option("SEAM_W24_NT", 2 if forced else 0)
+        if lib.seam_wino24_form(n, h, w, c, k, pad) != 1:
+            if forced:
+                continue
+            # natural dispatch: grow the batch until the launcher picks the producer / consumer kernel (it wants >= 1024 blocks)
+            n2 = n
+            while n2 * h * w * max(c, k) < (48 << 20) and lib.seam_wino24_form(n2, h, w, c, k, pad) != 1:
+                n2 = n2 * 2 + 1
+            if n2 > 3000 or lib.seam_wino24_form(n2, h, w, c, k, pad) != 1:
+                continue
+            n = n2
+        done += 1
+        g = gen(rng)
+        relu = rng.choice([0, 1, 1])
+        res_mode = rng.choice([0, 0, 1, 2])
+        ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+        slots = int(lib.seam_wino24_issue_slots(n, h, w, c, k, pad)) // (2 * 32 * 24)       # tiles of the launch
+        small += slots < 256
+        xcd1 += slots <= 8
+        mid += (slots % 8) != 0
+        desc = f"n={n} {h}x{w} c={c} k={k} pad={pad} relu={relu} res={res_mode} forced_nt2={int(forced)} tiles={slots}"
+        say("START wino24pc", desc)
+        x = torch.randn(n, h, w, c, device=dev, generator=g)
+        wt = torch.randn(k, c, 3, 3, device=dev, generator=g) / math.sqrt(9 * c)
+        scale, shift = epilogue_vectors(rng, k, g)
+        res = torch.randn(n, ho, wo, k, device=dev, generator=g) if res_mode else None
+        mode = 2 if res_mode == 2 else relu
+        pc = ops.pack_conv(wt, None, None, stride=1, pad=pad)
+        outs = []
+        for rep in range(2):
+            y = poisoned((n, ho, wo, k), torch.float32, rep)
+            rc = lib.seam_conv3x3_wino24_f32(P(x), P(pc.u24), P(scale), P(shift), P(res), P(y), n, h, w, c, k, pad, mode, st())
+            assert rc == 0, (desc, rc)
+            outs.append(y)
+        yi = poisoned((n, ho, wo, k), torch.float32, 0)
+        rc = lib.seam_conv2d_f32(P(x), P(pc.w), P(scale), P(shift), P(res), P(yi), n, h, w, c, k, 3, 3, 1, pad, mode, st())
+        assert rc == 0, (desc, rc)
+        refs = [("implicit GEMM", yi), ("torch fp32 (tap-wise matmul)", torch_epilogue(torch_conv3x3(x, wt, pad), scale, shift, res, mode))]
+        if conv_checked < 10 and n * h * w * c < (2 << 20):
+            conv_checked += 1
+            refs.append(("torch F.conv2d", torch_epilogue(F.conv2d(x.permute(0, 3, 1, 2), wt, None, 1, pad).permute(0, 2, 3, 1), scale, shift, res, mode)))
+        check("wino24pc", desc, outs[0], outs[1], refs, 3e-5)
+    _native.set_option("SEAM_W24_NT", 0)
+    # unserved channel counts: refused, not launched (pointers are never dereferenced)
+    dummy = torch.zeros(1 << 16, device=dev)
+    for (c, k) in [(60, 64), (64, 48), (4, 64), (64, 16), (0, 64)]:
+        rc = lib.seam_conv3x3_wino24_f32(P(dummy), P(dummy), None, None, None, P(dummy), 1, 8, 8, c, k, 1, 0, st())
+        if rc == 0:
+            fails.append(("wino24pc", f"c={c} k={k}", "unserved channel count was not refused"))
+    # the launcher caps.  An image of >= 2^31 bytes: refused ...
+    rc = lib.seam_conv3x3_wino24_f32(P(dummy), P(dummy), None, None, None, P(dummy), 1, 210, 210, 12224, 64, 1, 0, st())
+    if rc == 0:
+        fails.append(("wino24pc", "210x210x12224", "an image of >= 2^31 bytes was not refused"))
+    # ... more than 2^24 blocks: refused ...
+    rc = lib.seam_conv3x3_wino24_f32(P(dummy), P(dummy), None, None, None, P(dummy), 3000, 210, 210, 64, 2048, 1, 0, st())
+    if rc == 0:
+        fails.append(("wino24pc", "3000x210x210 k=2048", ">= 2^24 blocks were not refused"))
+    # ... and the largest image under the byte cap runs (24-bit multiplies at their largest operands): 210 x 210 x 12160 x 4 B = 2^31 - 2.4 MB
+    _native.set_option("SEAM_W24_NT", 2)
+    n, h, w, c, k, pad = 1, 210, 210, 12160, 64, 1
+    if lib.seam_wino24_form(n, h, w, c, k, pad) == 1:
+        desc = f"n={n} {h}x{w} c={c} k={k} pad={pad} (just under the 2^31-byte cap)"
+        say("START wino24pc", desc)
+        g = gen(rng)
+        x = torch.randn(n, h, w, c, device=dev, generator=g)
+        wt = torch.randn(k, c, 3, 3, device=dev, generator=g) / math.sqrt(9 * c)
+        pc = ops.pack_conv(wt, None, None, stride=1, pad=pad)
+        outs = []
+        for rep in range(2):
+            y = poisoned((n, h, w, k), torch.float32, rep)
+            rc = lib.seam_conv3x3_wino24_f32(P(x), P(pc.u24), None, None, None, P(y), n, h, w, c, k, pad, 0, st())
+            assert rc == 0, (desc, rc)
+            outs.append(y)
+        check("wino24pc", desc, outs[0], outs[1], [("torch fp32 (tap-wise matmul)", torch_conv3x3(x, wt, pad))], 3e-5)
+        del x, wt, pc, outs
+    else:
+        fails.append(("wino24pc", "210x210x12160", "the largest image under the cap is not served"))
+    _native.set_option("SEAM_W24_NT", 0)
+    say(f"SUMMARY wino24pc cases {done} grids<256 {small} grids<=8 {xcd1} ragged-XCD-ranges {mid} F.conv2d-checked {conv_checked} "
+        f"seconds {time.time() - t0:.1f}")
+
+
+# ------------------------------------------------------------------------------------------------ conv1x1_pc
+def stress_pwpc(rng):
+    t0 = time.time()
+    done = exact = conv_checked = 0
+    while done < NCASE:
+        c = rng.choice([256, 384, 512, 640, 768, 1024, 1536, 2048])
+        k = rng.choice([128, 256, 384, 512, 1024, 2048])
+        h, w = dim(rng, 1, 120), dim(rng, 1, 120)
+        n = pick_n(rng, h * w * max(c, k), 3 << 20)
+        m = n * h * w
+        if lib.seam_conv1x1_pc_supported(m, c, k) != 1:
+            continue
+        done += 1
+        g = gen(rng)
+        relu = rng.choice([0, 1])
+        use_res = rng.random() < 0.4
+        desc = f"M={m} c={c} k={k} relu={relu} res={int(use_res)}"
+        say("START conv1x1_pc", desc)
+        x = torch.randn(m, c, device=dev, generator=g)
+        wt = torch.randn(k, c, device=dev, generator=g) / math.sqrt(c)
+        scale, shift = epilogue_vectors(rng, k, g)
+        res = torch.randn(m, k, device=dev, generator=g) if use_res else None
+        wq = torch.empty((int(lib.seam_conv1x1_pc_weight_floats(k, c)),), dtype=torch.float32, device=dev)
+        assert lib.seam_pack_conv1x1_pc_f32(P(wt), P(wq), k, c, st()) == 0
+        wi = torch.empty((lib.seam_conv_rows_padded(k), lib.seam_conv_kred(c, 1, 1)), dtype=torch.float32, device=dev)
+        assert lib.seam_pack_conv_weight_f32(P(wt), P(wi), k, c, 1, 1, c, 0, st()) == 0
+        outs = []
+        for rep in range(2):
+            y = poisoned((m, k), torch.float32, rep)
+            rc = lib.seam_conv1x1_pc_f32(P(x), P(wq), P(scale), P(shift), P(res), P(y), m, c, k, relu, st())
+            assert rc == 0, (desc, rc)
+            outs.append(y)
+        yi = poisoned((m, k), torch.float32, 0)
+        assert lib.seam_conv2d_f32(P(x), P(wi), P(scale), P(shift), P(res), P(yi), 1, 1, m, c, k, 1, 1, 1, 0, relu, st()) == 0
+        exact += bool(torch.equal(outs[0], yi))
+        refs = [("implicit GEMM", yi), ("torch fp32 matmul", torch_epilogue(x @ wt.t(), scale, shift, res, relu))]
+        if conv_checked < 10:
+            conv_checked += 1
+            refs.append(("torch F.conv2d", torch_epilogue(F.conv2d(x.t().reshape(1, c, m, 1), wt[:, :, None, None])[0, :, :, 0].t(), scale, shift, res, relu)))
+        check("conv1x1_pc", desc, outs[0], outs[1], refs, 2e-5)
+    dummy = torch.zeros(1 << 16, device=dev)
+    for (c, k) in [(320, 128), (128, 128), (256, 192), (512, 64)]:
+        if lib.seam_conv1x1_pc_f32(P(dummy), P(dummy), None, None, None, P(dummy), 64, c, k, 0, st()) == 0:
+            fails.append(("conv1x1_pc", f"c={c} k={k}", "unserved channel count was not refused"))
+    say(f"SUMMARY conv1x1_pc cases {done} bit-identical-to-implicit-GEMM {exact} seconds {time.time() - t0:.1f}")
+    if exact != done:
+        fails.append(("conv1x1_pc", "-", f"only {exact} of {done} results bit-identical to the implicit GEMM (same k order claimed)"))
+
+
+# ------------------------------------------------------------------------------------------------ conv3x3_f16pc
+def stress_f16pc(rng):
+    t0 = time.time()
+    done = conv_checked = 0
+    while done < NCASE:
+        if rng.random() < 0.5:
+            h, w = dim(rng, 3, 120), dim(rng, 26, 210)
+        else:
+            w = rng.choice([3, 4, 6, 8, 10, 12, 13, 14, 16, 17, 18])
+            h = w if rng.random() < 0.7 else rng.choice([3, 5, 6, 8, 10, 12, 14, 16, 18])
+        pad = rng.randint(0, 1)
+        c, k = rng.choice([128, 256, 384, 512]), rng.choice([128, 256, 384, 1024])
+        if h + 2 * pad < 3 or w + 2 * pad < 3:
+            continue
+        n = pick_n(rng, h * w * max(c, k), 4 << 20)
+        if lib.seam_conv3x3_f16pc_supported(n, h, w, c, k, pad) != 1:
+            continue
+        done += 1
+        g = gen(rng)
+        relu = rng.choice([0, 1, 1])
+        ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+        desc = f"n={n} {h}x{w} c={c} k={k} pad={pad} relu={relu}"
+        say("START f16pc", desc)
+        x = torch.randn(n, h, w, c, device=dev, generator=g).half()
+        wt = (torch.randn(k, c, 3, 3, device=dev, generator=g) / math.sqrt(9 * c)).half().float()
+        scale, shift = epilogue_vectors(rng, k, g)
+        wh = torch.empty((int(lib.seam_f16pc_weight_halves(k, c)),), dtype=torch.float16, device=dev)
+        assert lib.seam_pack_conv_weight_f16pc(P(wt), P(wh), k, c, c, st()) == 0
+        wi = torch.empty((lib.seam_conv_rows_padded(k), lib.seam_conv_kred_f16(c, 3, 3)), dtype=torch.float16, device=dev)
+        assert lib.seam_pack_conv_weight_f16(P(wt), P(wi), k, c, 3, 3, c, 0, st()) == 0
+        outs = []
+        for rep in range(2):
+            y = poisoned((n, ho, wo, k), torch.float16, rep)
+            rc = lib.seam_conv3x3_f16pc(P(x), P(wh), P(scale), P(shift), None, P(y), n, h, w, c, k, pad, relu, st())
+            assert rc == 0, (desc, rc)
+            outs.append(y)
+        yi = poisoned((n, ho, wo, k), torch.float16, 0)
+        assert lib.seam_conv2d_f16(P(x), P(wi), P(scale), P(shift), None, P(yi), n, h, w, c, k, 3, 3, 1, pad, relu, 0, st()) == 0
+        refs = [("implicit GEMM (fp16)", yi), ("torch fp32 (tap-wise matmul)", torch_epilogue(torch_conv3x3(x, wt, pad), scale, shift, None, relu))]
+        if conv_checked < 10 and n * h * w * c < (2 << 20):
+            conv_checked += 1
+            refs.append(("torch F.conv2d", torch_epilogue(F.conv2d(x.float().permute(0, 3, 1, 2), wt, None, 1, pad).permute(0, 2, 3, 1), scale, shift, None, relu)))
+        check("f16pc", desc, outs[0], outs[1], refs, 2e-3)
+    dummy = torch.zeros(1 << 16, device=dev)
+    for (c, k) in [(64, 128), (128, 64), (192, 128), (136, 128)]:
+        if lib.seam_conv3x3_f16pc(P(dummy), P(dummy), None, None, None, P(dummy), 2, 14, 14, c, k, 1, 1, st()) == 0:
+            fails.append(("f16pc", f"c={c} k={k}", "unserved channel count was not refused"))
+    if lib.seam_conv3x3_f16pc(P(dummy), P(dummy), None, None, P(dummy), P(dummy), 2, 14, 14, 128, 128, 1, 1, st()) == 0:
+        fails.append(("f16pc", "residual", "a residual operand was not refused"))
+    say(f"SUMMARY f16pc cases {done} seconds {time.time() - t0:.1f}")
+
+
+# ------------------------------------------------------------------------------------------------ conv1x1_sw
+def stress_sw(rng):
+    t0 = time.time()
+    done = conv_checked = 0
+    while done < NCASE:
+        c = rng.choice([32, 64, 96, 128, 160, 192, 224, 256])
+        k = rng.choice([64, 128, 192, 256, 512, 1024, 2048])
+        h, w = dim(rng, 1, 150), dim(rng, 1, 150)
+        n = pick_n(rng, h * w * max(c, k), 3 << 20)
+        m = n * h * w
+        dual = c % 64 == 0 and rng.random() < 0.25
+        c1, c2 = (c // 2, c // 2) if dual else (c, 0)
+        if lib.seam_conv1x1_sw_config(m, c1, c2, k) == 0:
+            continue
+        done += 1
+        g = gen(rng)
+        relu = rng.choice([0, 1])
+        res_mode = 0 if dual else rng.choice([0, 0, 1, 2])
+        desc = f"n={n} {h}x{w} c={c1}+{c2} k={k} relu={relu} res_mode={res_mode} cfg={lib.seam_conv1x1_sw_config(m, c1, c2, k)}"
+        say("START conv1x1_sw", desc)
+        x = torch.randn(n, h, w, c, device=dev, generator=g)
+        wt = torch.randn(k, c, device=dev, generator=g) / math.sqrt(c)
+        shift = torch.randn(k, device=dev, generator=g) * 0.2
+        rh, rw = (h + 1) // 2, (w + 1) // 2
+        res = None
+        if res_mode == 1:
+            res = torch.randn(n, h, w, k, device=dev, generator=g)
+        elif res_mode == 2:
+            res = torch.randn(n, rh, rw, k, device=dev, generator=g)
+        xa = x[..., :c1].contiguous() if dual else x
+        xb = x[..., c1:].contiguous() if dual else None
+        outs = []
+        for rep in range(2):
+            y = poisoned((n, h, w, k), torch.float32, rep)
+            rc = lib.seam_conv1x1_sw_f32(P(xa), P(xb), P(wt), P(shift), P(res), P(y), m, c1, c2, k, relu, res_mode,
+                                         h if res_mode == 2 else 0, w if res_mode == 2 else 0, rh if res_mode == 2 else 0,
+                                         rw if res_mode == 2 else 0, st())
+            assert rc == 0, (desc, rc)
+            outs.append(y)
+        full = res
+        if res_mode == 2:
+            full = F.interpolate(res.permute(0, 3, 1, 2), size=(h, w), mode="nearest").permute(0, 2, 3, 1)
+        acc = (x.reshape(m, c) @ wt.t()).view(n, h, w, k)
+        refs = [("torch fp32 matmul", torch_epilogue(acc, None, shift, full, relu))]
+        wi = torch.empty((lib.seam_conv_rows_padded(k), lib.seam_conv_kred(c, 1, 1)), dtype=torch.float32, device=dev)
+        assert lib.seam_pack_conv_weight_f32(P(wt), P(wi), k, c, 1, 1, c, 0, st()) == 0
+        yi = poisoned((n, h, w, k), torch.float32, 0)
+        fr = full.contiguous() if full is not None else None
+        assert lib.seam_conv2d_f32(P(x), P(wi), None, P(shift), P(fr), P(yi), n, h, w, c, k, 1, 1, 1, 0, relu, st()) == 0
+        refs.append(("implicit GEMM", yi))
+        if conv_checked < 10:
+            conv_checked += 1
+            refs.append(("torch F.conv2d", torch_epilogue(F.conv2d(x.permute(0, 3, 1, 2), wt[:, :, None, None]).permute(0, 2, 3, 1), None, shift, full, relu)))
+        check("conv1x1_sw", desc, outs[0], outs[1], refs, 2e-5)
+    dummy = torch.zeros(1 << 16, device=dev)
+    for (c, k) in [(288, 64), (64, 96), (48, 64), (64, 768), (64, 8448)]:
+        if lib.seam_conv1x1_sw_f32(P(dummy), None, P(dummy), P(dummy), None, P(dummy), 64, c, 0, k, 0, 0, 0, 0, 0, 0, st()) == 0:
+            fails.append(("conv1x1_sw", f"c={c} k={k}", "unserved channel count was not refused"))
+    say(f"SUMMARY conv1x1_sw cases {done} seconds {time.time() - t0:.1f}")
+
+
+for idx, (name, fn) in enumerate([("wino24pc", stress_wino24pc), ("conv1x1_pc", stress_pwpc), ("f16pc", stress_f16pc), ("conv1x1_sw", stress_sw)]):
+    if len(sys.argv) > 3 and name not in sys.argv[3:]:
+        continue
+    before = len(fails)
+    fn(random.Random(SEED * 7919 + idx))
+    torch.cuda.synchronize()
+    say("KERNEL", name, "failures", len(fails) - before)
+say("DONE failures", len(fails))
+for f in fails[:40]:
+    say("FAILED", *f)
+sys.exit(1 if fails else 0)
+'''
+
+
+@pytest.fixture(scope="module")
+def sweep():
+    """One child process runs all four sweeps (one ``import torch``); its stdout is what the tests below read."""
+    env = dict(os.environ)
+    try:
+        r = subprocess.run([sys.executable, "-c", _CHILD, str(NCASE), "6"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=WALL_S)
+        return {"rc": r.returncode, "out": r.stdout, "err": r.stderr, "hung": False}
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        err = e.stderr.decode() if isinstance(e.stderr, bytes) else (e.stderr or "")
+        return {"rc": -1, "out": out, "err": err, "hung": True}
+
+
+def _kernel_ok(sweep, name):
+    out = sweep["out"]
+    starts = [ln for ln in out.splitlines() if ln.startswith("START")]
+    if sweep["hung"]:
+        pytest.fail(f"the sweep did not finish in {WALL_S} s -- last shape started: {starts[-1] if starts else '(none)'}")
+    line = [ln for ln in out.splitlines() if ln.startswith(f"KERNEL {name} ")]
+    assert line, f"sweep of {name} did not run to its end (rc {sweep['rc']}); last shape started: {starts[-1] if starts else '(none)'}\n" \
+                 + out[-1500:] + sweep["err"][-3000:]
+    failed = [ln for ln in out.splitlines() if ln.startswith("FAIL") and f" {name} " in ln]
+    assert line[0].split()[-1] == "0", "\n".join(failed[:20])
+    summary = [ln for ln in out.splitlines() if ln.startswith(f"SUMMARY {name} ")]
+    assert summary and int(summary[0].split()[3]) >= NCASE, summary
+    return summary[0]
+
+
+def test_stress_conv3x3_wino24pc(sweep):
+    s = _kernel_ok(sweep, "wino24pc").split()
+    # the sweep really reached the small-grid corners
+    assert int(s[5]) >= 20 and int(s[7]) >= 5 and int(s[9]) >= 20, s
+
+
+def test_stress_conv1x1_pc(sweep):
+    _kernel_ok(sweep, "conv1x1_pc")
+
+
+def test_stress_conv3x3_f16pc(sweep):
+    _kernel_ok(sweep, "f16pc")
+
+
+def test_stress_conv1x1_sw(sweep):
+    _kernel_ok(sweep, "conv1x1_sw")
+
+
+def test_stress_sweep_is_fast(sweep):
+    """<= 90 s of sweep (VERDICT's bound), measured inside the child (process start-up and ``import torch`` excluded)."""
+    secs = [float(ln.split()[-1]) for ln in sweep["out"].splitlines() if ln.startswith("SUMMARY")]
+    assert len(secs) == 4 and sum(secs) <= 90.0, secs

@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   rm -rf $L; mkdir -p $L
   for v in "$@"; do
     name=${v%%:*}; flags=$(echo "${v#*:}" | sed 's/,/ -D/g; s/^/-D/')
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude $flags -c $C/seam_pwpc.hip -o /tmp/pwpc_$name.o || exit 1
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -DSEAM_DEV_BUILD $flags -c $C/seam_pwpc.hip -o /tmp/pwpc_$name.o || exit 1
     hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v seam_pwpc.o) /tmp/pwpc_$name.o -o $L/libseam_$name.so || exit 1
   done
 else

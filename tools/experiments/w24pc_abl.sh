@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   rm -rf $L; mkdir -p $L
   for v in "$@"; do
     name=${v%%:*}; flags=$(echo "${v#*:}" | sed 's/,/ -D/g; s/^/-D/')
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude $flags -c $C/seam_wino24.hip -o /tmp/w24pc_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A8 "wino24pc" | grep "VGPRs:\|ScratchSize\|Occupancy" | tr '\n' ' '; echo " <- $name"
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -DSEAM_DEV_BUILD $flags -c $C/seam_wino24.hip -o /tmp/w24pc_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A8 "wino24pc" | grep "VGPRs:\|ScratchSize\|Occupancy" | tr '\n' ' '; echo " <- $name"
     hipcc --offload-arch=gfx950 -shared -fPIC $(ls $C/build/*.o | grep -v seam_wino24.o) /tmp/w24pc_$name.o -o $L/libseam_$name.so || exit 1
   done
 else
