@@ -24,6 +24,7 @@ enum Id {
     CONV_DYNLDS,       // default 0
     PW_BLOCKS,         // blocks of conv1x1_sw, default 256 (a multiple of 64)
     WINO_MT,           // 0 (default): F(2x2) launcher picks its m-tile form; 1 | 2 force it
+    WINO_NSPLIT,       // 0 (default): the F(2x2) launcher splits the n-tiles over XCD groups by its weight-footprint rule; > 0 forces it
     ROIALIGN_LDS,      // 2 (default): LDS-staged ROI quadrant tiles; 1: row-staged tiles; 0: gather kernel (profiles/r03_roialign_ab.txt)
     COUNT
 };
@@ -32,7 +33,7 @@ struct Entry { const char* name; int dflt; };
 constexpr Entry kTable[COUNT] = {
     {"SEAM_W24_PC", 1}, {"SEAM_W24_NT", 0}, {"SEAM_W24_PERSIST", 1}, {"SEAM_W24_NSPLIT", 0}, {"SEAM_W24_DYNLDS", 0}, {"SEAM_W24_WLDS", 1},
     {"SEAM_CONV_TILE", 0}, {"SEAM_F16_VEC_EPILOGUE", 1}, {"SEAM_EPI_PRIO", 1}, {"SEAM_CONV_SLOTS", 512}, {"SEAM_CONV_DYNLDS", 0},
-    {"SEAM_PW_BLOCKS", 256}, {"SEAM_WINO_MT", 0}, {"SEAM_ROIALIGN_LDS", 2},
+    {"SEAM_PW_BLOCKS", 256}, {"SEAM_WINO_MT", 0}, {"SEAM_WINO_NSPLIT", 0}, {"SEAM_ROIALIGN_LDS", 2},
 };
 
 extern std::atomic<int> g_value[COUNT];      // seam_abi.hip

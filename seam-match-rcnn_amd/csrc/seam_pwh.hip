@@ -1,0 +1,313 @@
+// seam_pwh.hip -- pointwise (1x1, stride 1) convolution in fp16 (fp32 accumulate) as a STREAMING kernel: weights stationary in LDS,
+// activation rows in and out as 16-byte NHWC pieces, independent waves (round 6).
+//
+// On the config-5 (fp16) path the 1x1 layers of the ResNet bottlenecks, the FPN laterals and the heads are HBM-bound: a pixel of the
+// 64 -> 256 expansion moves 128 + 512 (+ 512 residual) bytes for 32 k FLOP.  On the implicit GEMM (conv_igemm<_Float16,128,*>) they ran
+// at 0.23-0.83 of the HBM roof (profiles/r05_breakdown_c5_f16.txt: 49 launches, 85 of the step's 182 ms): a 128 x 128 tile's whole K
+// loop is 1-16 chunks of ~130 cycles each -- the tile is all prologue and epilogue, the four waves of a block meet at a barrier per
+// chunk and leave the memory pipe idle while they finish a tile together.
+//
+// This is the fp16 twin of seam_pw.hip (conv1x1_sw, exact fp32), with the same three properties:
+//   * a block (8 waves, one per CU) copies its SLAB of the weight matrix -- NS = 32 NT output channels x C halves, <= 135 KB -- and
+//     the slab's scale / shift vectors into LDS once and never meets a barrier again;
+//   * every wave owns whole pixel rows: a wave tile is 32 MT pixels x NS channels (<= 128 fp32 accumulators).  A fragments come
+//     straight from global memory in MFMA layout (v_mfma_f32_32x32x16_f16: lane = pixel row, 16 bytes = 8 consecutive k) through a
+//     4-deep ring that runs ACROSS tile boundaries -- the loads of the next tile are in flight while this one is finished -- and B
+//     fragments from the slab with ds_read_b128;
+//   * the epilogue IS the loop: per half MFMA tile (16 pixels x 32 channels) a wave-private 2 KB LDS transpose turns the accumulator
+//     layout into rows, a lane finishes 8 consecutive channels of one pixel (scale / shift in fp32, residual, ReLU, one rounding to
+//     fp16) and stores them as ONE 16-byte piece; residual pieces are requested three steps ahead.  Nothing waits for anything but
+//     its own loads, and the other seven waves of the CU are at unrelated points of their own tiles.
+// Arithmetic: the same products as seam_conv2d_f16 (fp16 operands, fp32 accumulation, fp32 scale / shift / residual, one rounding),
+// accumulated in a different order: results agree to fp32 rounding of the accumulation, not bit for bit; an output is one wave's
+// fixed fma chain, so results are deterministic and independent of M.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <stdint.h>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ f32x4 lds_read16(int addr) { return *reinterpret_cast<lds_f32x4*>((unsigned)addr); }
+
+constexpr int PWH_WAVES = 8;
+constexpr int TBUF = 16 * 128;          // wave-private transpose buffer: 16 pixel rows x 32 channels fp32
+constexpr int RESQ = 3;                 // residual pieces in flight (epilogue steps ahead)
+
+struct PwhArgs {
+    const _Float16* x;     // [M, C1]
+    const _Float16* x2;    // [M, C2] or null: second source of the reduction (stride-1 projection-shortcut block)
+    const _Float16* w;     // [K, C1 + C2] row-major fp16
+    const float* scale;    // [K] or null (= 1)
+    const float* shift;    // [K] or null (= 0)
+    const _Float16* res;   // [M, K] or null
+    _Float16* y;           // [M, K]
+    int M, C1, C2, K;
+    int relu;
+    int ns;                // weight slabs = K / NS
+};
+
+template <int MT, int NT, bool DUAL, bool RES>
+__global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = 32 * NT;
+    const int Ct = DUAL ? p.C1 + p.C2 : p.C1;
+    const int LDW = Ct * 2 + 16;                 // slab row: odd number of 16-byte slots => conflict-free ds_read_b128 fragments
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int slab = (b >> 3) % p.ns;
+    const int grp = (b >> 3) / p.ns;             // this block's index among the blocks of (xcd, slab)
+    const int gpb = ((int)gridDim.x >> 3) / p.ns;
+    const int n0 = slab * NS;
+
+    // ---- the weight slab and its epilogue vectors -> LDS, once -----------------------------------------------------------
+    float* const vec = reinterpret_cast<float*>(smem + NS * LDW + PWH_WAVES * TBUF);       // [2][NS]: scale, shift
+    {
+        const int vpr = Ct >> 3;                 // 16-byte pieces per row
+        const int total = NS * vpr;
+        for (int v = tid; v < total; v += 64 * PWH_WAVES) {
+            const int r = v / vpr, c8 = v - r * vpr;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(p.w + (size_t)(n0 + r) * Ct + c8 * 8);
+            *reinterpret_cast<f32x4*>(smem + r * LDW + c8 * 16) = val;
+        }
+        for (int v = tid; v < NS; v += 64 * PWH_WAVES) {
+            vec[v] = p.scale ? p.scale[n0 + v] : 1.f;
+            vec[NS + v] = p.shift ? p.shift[n0 + v] : 0.f;
+        }
+    }
+    __syncthreads();
+    char* const tb = smem + NS * LDW + wid * TBUF;
+
+    const int tiles = (p.M + 32 * MT - 1) / (32 * MT);
+    const int tiles_x = tiles > xcd ? (tiles - xcd + 7) >> 3 : 0;      // row tiles of this XCD: xcd, xcd + 8, ...
+    const int wstride = gpb * PWH_WAVES;
+    int tt = grp * PWH_WAVES + wid;
+    if (tt >= tiles_x) return;
+
+    const int nks = Ct >> 4;                     // k-steps of 16 channels (a multiple of 4: C1, C2 are multiples of 64)
+    const int nks1 = p.C1 >> 4;
+    // per-lane constants
+    const unsigned a_lane1 = (unsigned)((lane & 31) * p.C1 * 2 + (lane >> 5) * 16);
+    const unsigned a_lane2 = (unsigned)((lane & 31) * p.C2 * 2 + (lane >> 5) * 16);
+    const int b_lane = (int)(unsigned)(size_t)(lds_char*)smem + (lane & 31) * LDW + (lane >> 5) * 16;
+    // transpose buffer [16 rows][32 channels] fp32; 16-byte slot q of row r sits at slot q ^ (r & 1): a lane's two ds_read_b128
+    // (row l >> 2, slots 2 (l & 3) and 2 (l & 3) + 1) are conflict-free -- eight consecutive lanes = two rows = every bank once --
+    // and so are the ds_write_b32 of the accumulator layout (one row, a permutation of its 32 columns, per 32 lanes)
+    const int t_wr0 = ((lane >> 5) * 4) * 128 + ((lane & 31) >> 2) * 16 + (lane & 3) * 4;            // even rows: row 4*(l>>5) (+ reg rows), col l&31
+    const int t_wr1 = ((lane >> 5) * 4) * 128 + ((((lane & 31) >> 2)) ^ 1) * 16 + (lane & 3) * 4;    // odd rows
+    const int t_par = (lane >> 2) & 1;
+    const int t_rd0 = (lane >> 2) * 128 + (((lane & 3) * 2) ^ t_par) * 16;          // transpose read: row l>>2, channels (l&3)*8 .. +3
+    const int t_rd1 = (lane >> 2) * 128 + (((lane & 3) * 2 + 1) ^ t_par) * 16;      // ... +4 .. +7
+    const unsigned e_lane = (unsigned)((lane >> 2) * p.K * 2 + (lane & 3) * 16);   // y / residual: row l>>2, channels (l&3)*8
+    const float* const v_lane = vec + (lane & 3) * 8;
+
+    // A stream: (tile, k-step) pairs in order; loads run 4 k-steps ahead of the MFMAs, across tile boundaries.  The descriptor
+    // of the tile being fetched covers exactly its rows (rows past M and tiles past the end of this wave's list have no records:
+    // the loads stay unconditional and return zeros nobody uses)
+    f16x8 ring[4][MT];
+    int ld_tt = tt, ld_ks = 0;                   // position of the NEXT load of the stream
+    __amdgpu_buffer_rsrc_t ld_rs1, ld_rs2;
+    auto set_ld_tile = [&](int t) {
+        const int row0 = (xcd + 8 * t) * (32 * MT);
+        const int rows = t < tiles_x ? min(32 * MT, p.M - row0) : 0;
+        ld_rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)row0 * p.C1), 0, rows * p.C1 * 2, 0x00020000);
+        if constexpr (DUAL)
+            ld_rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 + (size_t)row0 * p.C2), 0, rows * p.C2 * 2, 0x00020000);
+    };
+    set_ld_tile(tt);
+    auto issue_a = [&](f16x8 (&slot)[MT]) {
+        if constexpr (DUAL) {
+            const bool second = ld_ks >= nks1;           // wave-uniform: scalar selects
+            const int Cs = second ? p.C2 : p.C1;
+            const int ks = second ? ld_ks - nks1 : ld_ks;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                slot[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(second ? ld_rs2 : ld_rs1, second ? a_lane2 : a_lane1,
+                                                                                         ks * 32 + i * 32 * Cs * 2, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                slot[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(ld_rs1, a_lane1, ld_ks * 32 + i * 32 * p.C1 * 2, 0));
+        }
+        if (++ld_ks == nks) { ld_ks = 0; ld_tt += wstride; set_ld_tile(ld_tt); }
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) issue_a(ring[s]);
+
+    f32x16 acc[MT][NT];
+    f16x8 fb[NT];
+    int bj[NT];                                  // B fragment pointers: slab row (32 j + l & 31), k-slot (l >> 5), current trip
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        bj[j] = b_lane + j * 32 * LDW;
+        asm volatile("" : "+v"(bj[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj[j]));
+
+    // four k-steps (one trip around the A ring).  FIRST: the tile's first trip multiplies into the constant 0
+    auto trip = [&](int ks0, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u == 3) {
+                const int inc = ks0 + 4 < nks ? 128 : -(nks - 4) * 32;      // past the last k-step: back to step 0 (the next tile's first)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bj[j] += inc;
+                    asm volatile("" : "+v"(bj[j]));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (FIRST && u == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[u][i], fb[j], z, 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[u][i], fb[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+                fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj[j] + (u < 3 ? (u + 1) * 32 : 0)));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            issue_a(ring[u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (; tt < tiles_x; tt += wstride) {
+        trip(0, std::true_type{});
+        for (int ks0 = 4; ks0 < nks; ks0 += 4) trip(ks0, std::false_type{});
+
+        // ---- epilogue: y = act(acc * scale + shift [+ residual]) -> fp16, through the wave-private transpose --------------
+        // Steps s = (i, h, j) = half an MFMA tile each: 16 pixel rows x 32 channels; a lane finishes row (l >> 2), 8 channels at
+        // (l & 3) * 8: one 16-byte store.  Loads are unconditional; the residual piece of step s + RESQ is requested before step s.
+        const int row0 = (xcd + 8 * tt) * (32 * MT);
+        const int ybytes = min(32 * MT, p.M - row0) * p.K * 2;       // rows past M: out of range (loads return 0, stores are dropped)
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)row0 * p.K), 0, ybytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((RES ? p.res : p.y) + (size_t)row0 * p.K), 0, ybytes, 0x00020000);
+        constexpr int STEPS = MT * 2 * NT;
+        auto soff_of = [&](int s) { return (16 * (s / NT) * p.K + n0 + 32 * (s % NT)) * 2; };      // wave-uniform byte offset of a step
+        u32x4 rv[RESQ];
+        auto request = [&](int s) {
+            if constexpr (RES) rv[s % RESQ] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, e_lane, soff_of(s), 0);
+        };
+        auto steps = [&](auto relu_tag) {
+            constexpr bool RELU = decltype(relu_tag)::value;
+#pragma unroll
+            for (int s = 0; s < RESQ && s < STEPS; ++s) request(s);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const int ih = s / NT, i = ih >> 1, h = ih & 1, j = s % NT;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    *reinterpret_cast<float*>(tb + ((r & 1) ? t_wr1 : t_wr0) + ((r & 3) + 8 * (r >> 2)) * 128) = acc[i][j][8 * h + r];
+                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(v_lane + 32 * j), sc1 = *reinterpret_cast<const f32x4*>(v_lane + 32 * j + 4);
+                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(v_lane + NS + 32 * j), sh1 = *reinterpret_cast<const f32x4*>(v_lane + NS + 32 * j + 4);
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(tb + t_rd0) * sc0 + sh0;
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(tb + t_rd1) * sc1 + sh1;
+                if constexpr (RES) {
+                    const f16x8 rh = __builtin_bit_cast(f16x8, rv[s % RESQ]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] += (float)rh[e]; v1[e] += (float)rh[e + 4]; }
+                    if (s + RESQ < STEPS) request(s + RESQ);
+                }
+                if constexpr (RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                }
+                f16x8 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hv[e] = (_Float16)v0[e]; hv[e + 4] = (_Float16)v1[e]; }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, e_lane, soff_of(s), 0);
+            }
+        };
+        if (p.relu) steps(std::true_type{});
+        else steps(std::false_type{});
+    }
+}
+
+// 0 = not served by this kernel (the caller stays on the implicit GEMM); otherwise MT * 100 + NT
+inline int pwh_config(long long M, int C1, int C2, int K) {
+    const int Ct = C1 + C2;
+    if (M <= 0 || M > 0x7fffffffLL / 64 || C1 <= 0 || (C1 % 64) || C2 < 0 || (C2 % 64) || Ct > 1024 || K <= 0 || (K % 64)) return 0;
+    const long room = 163840 - PWH_WAVES * TBUF;
+    auto fits = [&](int ns) { return (long)ns * (Ct * 2 + 16) + 2L * ns * 4 <= room; };
+    // (every branch needs its slab count K / NS to divide an XCD's 32 blocks: the block -> (slab, row group) decode walks the slabs
+    //  inside each XCD's blocks)
+    if (K % 256 == 0 && fits(256) && 32 % (K / 256) == 0) return 108;
+    if (K % 128 == 0 && fits(128) && 32 % (K / 128) == 0) return 204;
+    if (fits(64) && 32 % (K / 64) == 0) return 402;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// MT * 100 + NT of the wave tile seam_conv1x1_swh_f16 will use for [M, C1 + C2] x [K, C1 + C2]^T, or 0 when the shape is not served
+// (C1 / C2 not multiples of 64, C1 + C2 > 1024, K not a multiple of 64 or a slab count that does not divide 32).  Independent of M.
+int seam_conv1x1_swh_config(long long M, int C1, int C2, int K) { return pwh_config(M, C1, C2, K); }
+
+int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const float* scale, const float* shift, const void* residual,
+                         void* y, long long M, int C1, int C2, int K, int relu, void* stream) {
+    const int cfg = pwh_config(M, C1, C2, K);
+    if (!cfg || (C2 > 0 && !x2) || relu < 0 || relu > 1) return (int)hipErrorInvalidValue;
+    PwhArgs a;
+    a.x = (const _Float16*)x; a.x2 = (const _Float16*)x2; a.w = (const _Float16*)w; a.scale = scale; a.shift = shift;
+    a.res = (const _Float16*)residual; a.y = (_Float16*)y;
+    a.M = (int)M; a.C1 = C1; a.C2 = C2; a.K = K; a.relu = relu;
+    const int MT = cfg / 100, NT = cfg % 100;
+    a.ns = K / (32 * NT);
+    const int Ct = C1 + C2;
+    const size_t lds = (size_t)(32 * NT) * (Ct * 2 + 16) + PWH_WAVES * TBUF + 2 * (32 * NT) * 4;
+    const int max_blk = 256;
+    if (max_blk < 8 * a.ns) return (int)hipErrorInvalidValue;
+    const int tiles = (int)((M + 32 * MT - 1) / (32 * MT));
+    int per_slab = (((tiles + PWH_WAVES - 1) / PWH_WAVES + 7) / 8) * 8;
+    if (per_slab > max_blk / a.ns) per_slab = (max_blk / a.ns) & ~7;      // a multiple of 8 (one row group per XCD), >= 8
+    const int nblk = per_slab * a.ns;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+#define SEAM_PWH_LAUNCH(mt, nt, dual, res)                                                                                        \
+    do {                                                                                                                         \
+        static std::atomic<unsigned> attr_done{0};      /* one bit per device: the ABI is thread-safe per stream */               \
+        int dev_ = 0;                                                                                                            \
+        (void)hipGetDevice(&dev_);                                                                                               \
+        if (!(attr_done.load(std::memory_order_acquire) & (1u << (dev_ & 31)))) {                                                \
+            e = hipFuncSetAttribute((const void*)pw_swh_kernel<mt, nt, dual, res>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                    163840);                                                                                     \
+            if (e == hipSuccess) attr_done.fetch_or(1u << (dev_ & 31), std::memory_order_release);                               \
+        }                                                                                                                        \
+        if (e == hipSuccess) hipLaunchKernelGGL((pw_swh_kernel<mt, nt, dual, res>), dim3(nblk), dim3(64 * PWH_WAVES), lds, st, a); \
+    } while (0)
+#define SEAM_PWH_CFG(dual, res)                                                                                                   \
+    do {                                                                                                                         \
+        if (MT == 1 && NT == 8) SEAM_PWH_LAUNCH(1, 8, dual, res);                                                                \
+        else if (MT == 2 && NT == 4) SEAM_PWH_LAUNCH(2, 4, dual, res);                                                           \
+        else SEAM_PWH_LAUNCH(4, 2, dual, res);                                                                                   \
+    } while (0)
+    if (C2 > 0) {
+        if (residual) SEAM_PWH_CFG(true, true); else SEAM_PWH_CFG(true, false);
+    } else {
+        if (residual) SEAM_PWH_CFG(false, true); else SEAM_PWH_CFG(false, false);
+    }
+#undef SEAM_PWH_CFG
+#undef SEAM_PWH_LAUNCH
+    if (e != hipSuccess) return (int)e;
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -101,6 +101,9 @@ struct WinoArgs {
     int G;                // stacked mode: max images a block touches (else 1)
     int tiles_n;          // K / 32
     int nchunks;          // C / 8
+    // n-tile split over XCD groups (round 6): nsplit groups of XCDs, tns = tiles_n / nsplit n-tiles per group; the m-blocks are cut
+    // into 8 / nsplit partitions of part_q (+1 for the first part_r) each.  nsplit = 1: every XCD walks all n-tiles of its m-blocks.
+    int nsplit, tns, part_q, part_r;
 };
 
 template <int MT> struct WinoCfg {
@@ -125,10 +128,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(const WinoArgs p) {
     const int nblk = gridDim.x;
     const int b = blockIdx.x;
     const int xcd = b & 7;
-    const int q8 = nblk >> 3, rem8 = nblk & 7;
-    const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
-    const int tm = tile / p.tiles_n;
-    const int tn = tile - tm * p.tiles_n;
+    int tm, tn;
+    if (p.nsplit > 1) {
+        // A layer whose transformed weights (16 * K * C * 4 bytes) exceed an XCD's 4 MiB L2 re-streams ALL of them from the Infinity
+        // Cache for every generation of resident blocks when each XCD walks every n-tile (the 8x8 -> 6x6 x 1024 trunk conv: 16.8 MB
+        // of weights, 3.7 GB fetched per launch for 0.19 GB of input -- profiles/r05_pmc_traffic.json).  Split: XCD x (= blockIdx & 7)
+        // streams only the n-tile subset g = x % nsplit -- its share of the weights stays L2-resident -- and the XCDs of a group share
+        // partition pi = x / nsplit of the m-blocks; every input patch is then read by nsplit XCDs (patch loads run two chunks ahead
+        // and tolerate the miss).  The tile -> (tm, tn) map changes, no tile's arithmetic does: results are bit-identical.
+        const int g = xcd % p.nsplit, pi = xcd / p.nsplit;
+        const int j = b >> 3;
+        const int tml = j / p.tns;
+        tn = g * p.tns + (j - tml * p.tns);
+        const int size = p.part_q + (pi < p.part_r ? 1 : 0);
+        if (tml >= size) return;                           // padding blocks of the shorter partitions
+        tm = pi * p.part_q + min(pi, p.part_r) + tml;
+    } else {
+        const int q8 = nblk >> 3, rem8 = nblk & 7;
+        const int tile = (xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8) + (b >> 3);
+        tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+    }
     const int per_img = p.per_img;
     int rb = tm - (tm / per_img) * per_img;
     int reg = 0;                                           // region of this block (wave-uniform scalar work)
@@ -632,6 +652,21 @@ static int wino_plan(WinoArgs& a, int N, int H, int W, int C, int K, int pad, in
         a.TX[r] = pp.TX[q]; a.TY[r] = pp.TY[q]; a.bx[r] = pp.bx[q]; a.by[r] = pp.by[q];
     }
     blocks = pp.blocks * a.tiles_n;
+    {
+        // n-tile split (see the kernel's tile decode): as many XCD groups as it takes for a group's share of the weights to sit in
+        // its L2 beside the patches (<= 2.5 MB), when the launch is large enough for every group to keep its CUs busy
+        const int want = seam_opt::get(seam_opt::WINO_NSPLIT);      // 0: this rule; > 0: forced (experiments)
+        int ns = 1;
+        const size_t wbytes = (size_t)16 * K * C * 4;
+        if (want > 0) ns = want;
+        else while (ns < 8 && wbytes / ns > (size_t)2560 * 1024) ns <<= 1;
+        while (ns > 1 && (a.tiles_n % ns || 8 % ns || pp.blocks * (a.tiles_n / ns) < 8L * 64)) ns >>= 1;
+        a.nsplit = ns < 1 ? 1 : ns;
+        a.tns = a.tiles_n / a.nsplit;
+        const int parts = 8 / a.nsplit;
+        a.part_q = (int)(pp.blocks / parts); a.part_r = (int)(pp.blocks % parts);
+        if (a.nsplit > 1) blocks = 8L * (a.part_q + (a.part_r ? 1 : 0)) * a.tns;
+    }
     if (blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
     return 0;
 }
@@ -644,7 +679,8 @@ int seam_wino_slot_fill_pct(int N, int H, int W, int C, int K, int pad) {
     long blocks;
     if (wino_plan(a, N, H, W, C, K, pad, mt, blocks)) return 0;
     const double tiles = (double)N * ((a.Wo + 1) / 2) * ((a.Ho + 1) / 2) * a.tiles_n;
-    return (int)(100.0 * tiles / ((double)blocks * 32 * mt));
+    const long work = a.nsplit > 1 ? ((long)(8 / a.nsplit) * a.part_q + a.part_r) * a.tiles_n : blocks;     // without the padding blocks
+    return (int)(100.0 * tiles / ((double)work * 32 * mt));
 }
 
 /* MFMA issues of the launch in units of 32x32x8-channel position GEMMs (blocks x 32*MT tile slots x 16 positions; 0 =
@@ -654,7 +690,8 @@ long long seam_wino_issue_slots(int N, int H, int W, int C, int K, int pad) {
     int mt;
     long blocks;
     if (wino_plan(a, N, H, W, C, K, pad, mt, blocks)) return 0;
-    return (long long)blocks * 32 * mt * 16;
+    const long work = a.nsplit > 1 ? ((long)(8 / a.nsplit) * a.part_q + a.part_r) * a.tiles_n : blocks;
+    return (long long)work * 32 * mt * 16;
 }
 
 int seam_wino_tile_variant(int N, int H, int W, int C, int K, int pad) {     // MT of conv3x3_wino<MT> the launcher picks (0: unsupported)

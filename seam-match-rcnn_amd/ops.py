@@ -64,6 +64,7 @@ class PackedConv:
     shift_sw: Optional[torch.Tensor] = None   # ... and its shift vector (zeros when the layer has none)
     wq: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C >= 256 (a multiple of 128), K % 128 == 0: fragment-order weights of seam_conv1x1_pc_f32
     wh: Optional[torch.Tensor] = None   # fp16 stride-1 3x3 layers (C, K multiples of 128): fragment-order weights of seam_conv3x3_f16pc
+    wsh: Optional[torch.Tensor] = None  # fp16 1x1 / stride-1 layers (C multiple of 64, <= 1024): row-major fp16 [K, C] weights of seam_conv1x1_swh_f16
 
 
 BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
@@ -80,6 +81,9 @@ F16PC = _os.environ.get("SEAM_F16PC", "1") != "0"
 # pointwise kernel (csrc/seam_pwpc.hip); SEAM_PWPC=0 keeps them on the implicit GEMM.  Layers the weights-stationary kernel takes
 # (C <= 256) stay there.
 PWPC = _os.environ.get("SEAM_PWPC", "1") != "0"
+# fp16 path: the 1x1 / stride-1 layers through the streaming weights-stationary kernel (csrc/seam_pwh.hip, round 6); SEAM_PWH=0 keeps
+# them on the implicit GEMM.  Maps of >= SW_MIN_HW pixels only -- a function of the map, like the fp32 rule.
+SWH = _os.environ.get("SEAM_PWH", "1") != "0"
 F16PC_RULE = True      # dispatch by seam_conv3x3_f16pc_pays (False: every supported shape -- tests, tools/f16pc_ab.py)
 
 
@@ -154,6 +158,11 @@ def _sw_ok(pc: "PackedConv", h: int, w: int) -> bool:
 def _sw_launch(lib, x, x2, pc, residual, y, m, c1, c2, relu, res_mode=0, ho=0, wo=0, rh=0, rw=0):
     _native.check(lib.seam_conv1x1_sw_f32(_ptr(x), _ptr(x2), _ptr(pc.ws), _ptr(pc.shift_sw), _ptr(residual), _ptr(y), m, c1, c2, pc.K,
                                           int(relu), res_mode, ho, wo, rh, rw, _stream()), "seam_conv1x1_sw_f32")
+
+
+def _swh_variant(lib, m, c, k) -> str:
+    cfg = int(lib.seam_conv1x1_swh_config(m, c, 0, k))
+    return f"conv1x1_swh<{cfg // 100},{cfg % 100}>"
 
 
 def _sw_variant(lib, m, c, k) -> str:
@@ -250,7 +259,12 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         wq = torch.empty((int(lib.seam_conv1x1_pc_weight_floats(K, cs)),), dtype=F32, device=weight.device)
         _native.check(lib.seam_pack_conv1x1_pc_f32(_ptr(weight.reshape(K, cin).to(F32).contiguous()), _ptr(wq), K, cs, _stream()),
                       "seam_pack_conv1x1_pc_f32")
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw, wq, wh)
+    wsh = None
+    if (SWH and dtype == F16 and mode in (0, 1) and not is_linear and R == 1 and S == 1 and stride == 1 and pad == 0 and cs == cin
+            and lib.seam_conv1x1_swh_config(1 << 20, cs, 0, K)):
+        wm = weight.permute(2, 3, 1, 0).reshape(K, cin) if transposed2x2 else weight.reshape(K, cin)
+        wsh = wm.to(F16).contiguous()
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw, wq, wh, wsh)
 
 
 def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -> PackedConv:
@@ -438,7 +452,12 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
             and lib.seam_conv1x1_pc_supported(n * h * w, c, pc.K) == 1)
     f16pc = (pc.dtype == F16 and pc.wh is not None and F16PC and residual is None and out_hw is None and not out_f32 and relu in (0, 1, False, True)
              and (lib.seam_conv3x3_f16pc_pays if F16PC_RULE else lib.seam_conv3x3_f16pc_supported)(n, h, w, c, pc.K, pc.pad) == 1)
-    if narrow:
+    swh = (pc.dtype == F16 and pc.wsh is not None and SWH and out_hw is None and not out_f32 and h * w >= SW_MIN_HW
+           and relu in (0, 1, False, True))
+    if swh:
+        _native.check(lib.seam_conv1x1_swh_f16(_ptr(x), None, _ptr(pc.wsh), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
+                                               n * h * w, c, 0, pc.K, 1 if relu else 0, _stream()), "seam_conv1x1_swh_f16")
+    elif narrow:
         _native.check(lib.seam_linear_narrow_f32(_ptr(x), _ptr(pc.wn), _ptr(pc.shift), _ptr(y), n * h * w, c, pc.K, int(relu), _stream()),
                       "seam_linear_narrow_f32")
     elif sw:
@@ -474,7 +493,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     if trace is not None:
         e1.record()
         tile = lib.seam_conv_tile_taps(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K, pc.R * pc.S)
-        if narrow:
+        if swh:
+            variant = _swh_variant(lib, n * h * w, c, pc.K)
+        elif narrow:
             variant = "linear_narrow"
         elif sw:
             variant = _sw_variant(lib, n * h * w, c, pc.K)
@@ -574,8 +595,15 @@ def conv2d_dual(x1: torch.Tensor, x2: torch.Tensor, pc: PackedConv, stride2: int
         e0.record()
     lib = _native.lib()
     sw = dt == F32 and stride2 == 1 and (h2, w2) == (ho, wo) and _sw_ok(pc, ho, wo)
+    swh = (dt == F16 and stride2 == 1 and (h2, w2) == (ho, wo) and SWH and ho * wo >= SW_MIN_HW
+           and lib.seam_conv1x1_swh_config(n * ho * wo, c1, c2, pc.K) != 0)
+    if swh and pc.wsh is None:            # (the dual weights are packed as ONE [K, C1 + C2] matrix: take the fp16 rows from it once)
+        swh = False
     if sw:
         _sw_launch(lib, x1, x2, pc, None, y, n * ho * wo, c1, c2, relu)
+    elif swh:
+        _native.check(lib.seam_conv1x1_swh_f16(_ptr(x1), _ptr(x2), _ptr(pc.wsh), _ptr(pc.scale), _ptr(pc.shift), None, _ptr(y),
+                                               n * ho * wo, c1, c2, pc.K, 1 if relu else 0, _stream()), "seam_conv1x1_swh_f16")
     else:
         fn = lib.seam_conv2d_dual_f32 if dt == F32 else lib.seam_conv2d_dual_f16
         _native.check(fn(_ptr(x1), _ptr(x2), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, ho, wo, c1,
@@ -586,7 +614,7 @@ def conv2d_dual(x1: torch.Tensor, x2: torch.Tensor, pc: PackedConv, stride2: int
         if tile // 1000 == 256:
             tile = 128128
         es = x1.element_size()
-        trace.append((_sw_variant(lib, n * ho * wo, c1 + c2, pc.K) if sw else f"conv_igemm<{'float' if dt == F32 else '_Float16'},{tile // 1000},{tile % 1000}>", 2.0 * n * ho * wo * pc.K * (c1 + c2), e0, e1,
+        trace.append((_sw_variant(lib, n * ho * wo, c1 + c2, pc.K) if sw else _swh_variant(lib, n * ho * wo, c1 + c2, pc.K) if swh else f"conv_igemm<{'float' if dt == F32 else '_Float16'},{tile // 1000},{tile % 1000}>", 2.0 * n * ho * wo * pc.K * (c1 + c2), e0, e1,
                       (n, ho, wo, c1 + c2, pc.K, 1, 1),
                       float(es * (x1.numel() + n * ho * wo * c2 + pc.w.numel() + y.numel()))))
     return y

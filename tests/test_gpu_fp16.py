@@ -309,3 +309,98 @@ def test_stem_space_to_depth_f16(ops, hw):
     pc8 = ops.pack_conv(wt.to(d), None, bn_d, stride=2, pad=3, cstore=8, dtype=H)
     old = ops.conv2d(x8, pc8, relu=True)
     assert old.shape == got.shape and float((old.float() - got.float()).abs().max()) <= 2e-3 * float(old.float().abs().max())
+
+
+@pytest.mark.parametrize("case", [
+    # n, C, H, W, K, relu, bn, residual        wave tiles <1,8> (C <= 256, K % 256 == 0), <2,4> (C <= 512, K % 128 == 0), <4,2> (C <= 1024)
+    (3, 64, 41, 53, 256, True, True, True), (2, 256, 33, 31, 1024, True, True, True), (2, 256, 48, 72, 256, True, False, False),
+    (2, 128, 40, 56, 512, False, True, False), (3, 512, 25, 42, 128, True, True, False), (2, 512, 24, 42, 256, True, False, True),
+    (2, 1024, 24, 42, 256, True, True, False), (1, 1024, 15, 17, 512, False, False, True), (2, 256, 20, 20, 64, True, True, False),
+    (5, 64, 14, 14, 64, True, False, False), (1, 64, 200, 301, 256, True, True, True),
+])
+def test_pointwise_streaming_kernel_f16(ops, case):
+    """seam_conv1x1_swh_f16 (csrc/seam_pwh.hip, round 6: weights stationary in LDS, independent waves, 16-byte NHWC pieces) against
+    the fp32 convolution of the same fp16-rounded operands (the bound of the implicit-GEMM tests above), against
+    conv_igemm<_Float16> on the same packed layer (two fp32 accumulation orders + one rounding: <= 2 fp16 ulps of the scale),
+    repeated launches bit-identical, and an image alone == the same image inside the batch (an output is one wave's fixed chain)."""
+    import seam_match_rcnn_amd._native as native
+    d = dev()
+    n, c, hh, ww, k, relu, bn, use_res = case
+    assert native.lib().seam_conv1x1_swh_config(n * hh * ww, c, 0, k) != 0
+    x = rnd(700, (n, c, hh, ww)).half().float()
+    wt = (rnd(701, (k, c, 1, 1), "w") / math.sqrt(c)).half().float()
+    res = rnd(702, (n, k, hh, ww), "r").half().float() if use_res else None
+    if bn:
+        b = (torch.from_numpy(synth.uniform(synth.stream_id(703, "bw"), (k,), 0.5, 1.5)), rnd(704, (k,), "bb") * 0.1,
+             rnd(705, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(706, "rv"), (k,), 0.5, 1.5)))
+        pc = ops.pack_conv(wt.to(d), None, bn=tuple(t.to(d) for t in b), dtype=H)
+        sc = b[0] * (b[3] + 1e-5).rsqrt()
+        ref = F.conv2d(x, wt) * sc[None, :, None, None] + (b[1] - b[2] * sc)[None, :, None, None]
+    else:
+        bias = rnd(703, (k,), "b") * 0.1
+        pc = ops.pack_conv(wt.to(d), bias.to(d), dtype=H)
+        ref = F.conv2d(x, wt, bias)
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    assert pc.wsh is not None and hh * ww >= ops.SW_MIN_HW
+    xd = nhwc(x).half().to(d)
+    rd = nhwc(res).half().to(d) if use_res else None
+    saved, ops.CONV_TRACE = ops.SWH, []
+    try:
+        ops.SWH = True
+        got = ops.conv2d(xd, pc, relu, rd)
+        assert ops.CONV_TRACE[0][0].startswith("conv1x1_swh"), ops.CONV_TRACE[0][0]
+        ops.CONV_TRACE = None
+        assert got.dtype == H
+        assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
+        for _ in range(4):
+            assert torch.equal(ops.conv2d(xd, pc, relu, rd), got)
+        alone = ops.conv2d(xd[n - 1:].contiguous(), pc, relu, None if rd is None else rd[n - 1:].contiguous())
+        assert torch.equal(alone, got[n - 1:])
+        ops.SWH = False
+        other = ops.conv2d(xd, pc, relu, rd)
+        scale = float(other.float().abs().max())
+        assert float((got.float() - other.float()).abs().max()) <= 2.0 ** -9 * scale
+    finally:
+        ops.SWH, ops.CONV_TRACE = saved, None
+
+
+def test_pointwise_streaming_kernel_f16_dual_and_unserved(ops):
+    """The two-source form (stride-1 projection shortcut: [W_a | W_b] . [h ; x]) on the streaming kernel == the implicit GEMM's dual
+    form to rounding; unserved shapes (C not a multiple of 64, C > 1024, K / slab not dividing 32) are refused by the C ABI and stay
+    on the implicit GEMM in ops.conv2d."""
+    import seam_match_rcnn_amd._native as native
+    d = dev()
+    lib = native.lib()
+    n, hh, ww, c1, c2, k = 2, 37, 45, 64, 64, 256
+    h1, x2 = rnd(720, (n, c1, hh, ww)).half().float(), rnd(721, (n, c2, hh, ww)).half().float()
+    wa, wb = rnd(722, (k, c1, 1, 1), "w") / math.sqrt(c1), rnd(723, (k, c2, 1, 1), "w") / math.sqrt(c2)
+    bn = lambda s: (torch.from_numpy(synth.uniform(synth.stream_id(s, "bw"), (k,), 0.5, 1.5)), rnd(s + 1, (k,), "bb") * 0.1,      # noqa: E731
+                    rnd(s + 2, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(s + 3, "rv"), (k,), 0.5, 1.5)))
+    b1, b2 = bn(730), bn(740)
+    pcd = ops.pack_conv_dual(wa.to(d), tuple(t.to(d) for t in b1), wb.to(d), tuple(t.to(d) for t in b2), dtype=H)
+    assert pcd.wsh is not None
+    xa, xb = nhwc(h1).half().to(d), nhwc(x2).half().to(d)
+    saved, ops.CONV_TRACE = ops.SWH, []
+    try:
+        ops.SWH = True
+        got = ops.conv2d_dual(xa, xb, pcd, 1, relu=True)
+        assert ops.CONV_TRACE[0][0].startswith("conv1x1_swh"), ops.CONV_TRACE[0][0]
+        ops.CONV_TRACE = None
+        assert torch.equal(ops.conv2d_dual(xa, xb, pcd, 1, relu=True), got)
+        ops.SWH = False
+        other = ops.conv2d_dual(xa, xb, pcd, 1, relu=True)
+    finally:
+        ops.SWH, ops.CONV_TRACE = saved, None
+    assert float((got.float() - other.float()).abs().max()) <= 2.0 ** -9 * float(other.float().abs().max())
+    s1, s2 = b1[0] * (b1[3] + 1e-5).rsqrt(), b2[0] * (b2[3] + 1e-5).rsqrt()
+    ref = F.relu(F.conv2d(h1, wa) * s1[None, :, None, None] + F.conv2d(x2, wb) * s2[None, :, None, None]
+                 + ((b1[1] - b1[2] * s1) + (b2[1] - b2[2] * s2))[None, :, None, None])
+    assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=4e-3, atol_scale=2e-3)
+    dummy = torch.zeros(1 << 16, dtype=H, device=d)
+    for (c, kk) in [(96, 256), (2048, 256), (32, 64), (64, 96), (64, 8448 * 2)]:
+        assert lib.seam_conv1x1_swh_config(1000, c, 0, kk) == 0
+        assert lib.seam_conv1x1_swh_f16(dummy.data_ptr(), None, dummy.data_ptr(), None, None, None, dummy.data_ptr(), 64, c, 0, kk, 0,
+                                        torch.cuda.current_stream().cuda_stream) != 0

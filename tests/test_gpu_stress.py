@@ -1,8 +1,8 @@
 """Random-shape stress of the hand-scheduled kernels through the C ABI.
 
 ``conv3x3_wino24pc`` (persistent producer / consumer Winograd F(2x4,3x3), hand-counted ``vmcnt`` waits, a cross-tile software
-pipeline, cached per-region addresses, 24-bit multiplies guarded by launcher caps), ``conv1x1_pc``, ``conv3x3_f16pc`` and
-``conv1x1_sw`` each get >= 200 seeded random shapes: every launch goes onto a POISONED output, twice, and must be bit-identical;
+pipeline, cached per-region addresses, 24-bit multiplies guarded by launcher caps), ``conv1x1_pc``, ``conv3x3_f16pc``,
+``conv1x1_sw`` and ``conv1x1_swh`` (round 6) each get >= 200 seeded random shapes: every launch goes onto a POISONED output, twice, and must be bit-identical;
 results are compared with the implicit GEMM (``seam_conv2d_f32`` / ``_f16``) AND with a plain torch fp32 convolution of the same
 operands (tap-wise ``matmul`` form for every shape -- no per-shape MIOpen search -- and ``F.conv2d`` itself on a sample).
 Unserved channel counts must be REFUSED (non-zero return), not hang.  Shapes cover N in [1, 3000], H, W in [3, 210] including
@@ -399,7 +399,56 @@ def stress_sw(rng):
     say(f"SUMMARY conv1x1_sw cases {done} seconds {time.time() - t0:.1f}")
 
 
-for idx, (name, fn) in enumerate([("wino24pc", stress_wino24pc), ("conv1x1_pc", stress_pwpc), ("f16pc", stress_f16pc), ("conv1x1_sw", stress_sw)]):
+# ------------------------------------------------------------------------------------------------ conv1x1_swh (fp16)
+def stress_swh(rng):
+    t0 = time.time()
+    done = conv_checked = 0
+    while done < NCASE:
+        c = rng.choice([64, 128, 192, 256, 320, 512, 768, 1024])
+        k = rng.choice([64, 128, 256, 512, 1024, 2048])
+        h, w = dim(rng, 1, 150), dim(rng, 1, 150)
+        n = pick_n(rng, h * w * max(c, k), 3 << 20)
+        m = n * h * w
+        dual = c % 128 == 0 and rng.random() < 0.25
+        c1, c2 = (c // 2, c // 2) if dual else (c, 0)
+        if lib.seam_conv1x1_swh_config(m, c1, c2, k) == 0:
+            continue
+        done += 1
+        g = gen(rng)
+        relu = rng.choice([0, 1])
+        use_res = rng.random() < 0.4
+        desc = f"M={m} c={c1}+{c2} k={k} relu={relu} res={int(use_res)} cfg={lib.seam_conv1x1_swh_config(m, c1, c2, k)}"
+        say("START conv1x1_swh", desc)
+        x = torch.randn(m, c, device=dev, generator=g).half()
+        wt = (torch.randn(k, c, device=dev, generator=g) / math.sqrt(c)).half()
+        scale, shift = epilogue_vectors(rng, k, g)
+        res = torch.randn(m, k, device=dev, generator=g).half() if use_res else None
+        xa = x[:, :c1].contiguous() if dual else x
+        xb = x[:, c1:].contiguous() if dual else None
+        outs = []
+        for rep in range(2):
+            y = poisoned((m, k), torch.float16, rep)
+            rc = lib.seam_conv1x1_swh_f16(P(xa), P(xb), P(wt), P(scale), P(shift), P(res), P(y), m, c1, c2, k, relu, st())
+            assert rc == 0, (desc, rc)
+            outs.append(y)
+        acc = x.float() @ wt.float().t()
+        refs = [("torch fp32 matmul", torch_epilogue(acc, scale, shift, None if res is None else res.float(), relu))]
+        wi = torch.empty((lib.seam_conv_rows_padded(k), lib.seam_conv_kred_f16(c, 1, 1)), dtype=torch.float16, device=dev)
+        wf = wt.float()
+        assert lib.seam_pack_conv_weight_f16(P(wf), P(wi), k, c, 1, 1, c, 0, st()) == 0
+        yi = poisoned((m, k), torch.float16, 0)
+        assert lib.seam_conv2d_f16(P(x), P(wi), P(scale), P(shift), P(res), P(yi), 1, 1, m, c, k, 1, 1, 1, 0, relu, 0, st()) == 0
+        refs.append(("implicit GEMM (fp16)", yi))
+        check("conv1x1_swh", desc, outs[0], outs[1], refs, 2e-3)
+    dummy = torch.zeros(1 << 16, dtype=torch.float16, device=dev)
+    for (c, k) in [(96, 256), (2048, 256), (32, 64), (64, 96), (1088, 64)]:
+        if lib.seam_conv1x1_swh_f16(P(dummy), None, P(dummy), None, None, None, P(dummy), 64, c, 0, k, 0, st()) == 0:
+            fails.append(("conv1x1_swh", f"c={c} k={k}", "unserved channel count was not refused"))
+    say(f"SUMMARY conv1x1_swh cases {done} seconds {time.time() - t0:.1f}")
+
+
+for idx, (name, fn) in enumerate([("wino24pc", stress_wino24pc), ("conv1x1_pc", stress_pwpc), ("f16pc", stress_f16pc), ("conv1x1_sw", stress_sw),
+                                  ("conv1x1_swh", stress_swh)]):
     if len(sys.argv) > 3 and name not in sys.argv[3:]:
         continue
     before = len(fails)
@@ -459,7 +508,11 @@ def test_stress_conv1x1_sw(sweep):
     _kernel_ok(sweep, "conv1x1_sw")
 
 
+def test_stress_conv1x1_swh(sweep):
+    _kernel_ok(sweep, "conv1x1_swh")
+
+
 def test_stress_sweep_is_fast(sweep):
     """<= 90 s of sweep (VERDICT's bound), measured inside the child (process start-up and ``import torch`` excluded)."""
     secs = [float(ln.split()[-1]) for ln in sweep["out"].splitlines() if ln.startswith("SUMMARY")]
-    assert len(secs) == 4 and sum(secs) <= 90.0, secs
+    assert len(secs) == 5 and sum(secs) <= 90.0, secs
