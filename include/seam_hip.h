@@ -139,8 +139,8 @@ int seam_conv1x1_sw_f32(const float* x, const float* x2, const float* w, const f
  * seam_conv2d_dual_f16 (stride2 = 1) on those shapes:
  *   y[M,K] = fp16( act( [x | x2][M, C1 + C2] . w[K, C1 + C2]^T * scale + shift [+ residual[M,K]] ) )
  * x, x2, residual, y fp16; w fp16 row-major [K, C1 + C2]; scale / shift fp32 [K] or NULL; fp32 accumulation, fp32 epilogue, one
- * rounding.  Shapes served (seam_conv1x1_swh_config != 0): C1, C2 multiples of 64, C1 + C2 <= 1024 (<= 256 / 512 for the 256- /
- * 128-channel slabs), K a multiple of 64 with K / slab dividing 32; any M > 0.  relu 0 | 1.  Same products as seam_conv2d_f16 in a
+ * rounding.  Shapes served (seam_conv1x1_swh_config != 0): C1, C2 multiples of 64, C1 + C2 <= 512 (<= 256 for the 256-channel slab
+ * K % 256 == 0 takes, <= 128 when K is not a multiple of 128), K a multiple of 64 with K / slab dividing 32; any M > 0.  relu 0 | 1.  Same products as seam_conv2d_f16 in a
  * different accumulation order (agreement to fp32 rounding, not bit for bit); deterministic and independent of M. */
 int seam_conv1x1_swh_config(long long M, int C1, int C2, int K);
 int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const float* scale, const float* shift,

@@ -269,7 +269,12 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw_sw_kernel(const PwArgs p)
                             v[e] = o;
                         }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, e_lane, soff + q * 8 * p.K * 4, 0);
+                    // (the step offset rides in the VECTOR offset -- round 6: behind a 16-byte store with an SGPR offset hipcc places
+                    //  the next piece's arithmetic without the wait state the store's data registers need; tools/isa_store_hazard.py
+                    //  found `buffer_store_dwordx4 v[0:3], ..., s64 offen` / `v_pk_add_f32 v[2:3], ...` back to back in eight instances
+                    //  of this kernel.  No test ever saw a wrong value from it -- the s_waitcnt between the two happened to cover the
+                    //  read -- but seam_pwpc.hip (round 5) and seam_pwh.hip (round 6) did.)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, e_lane + (unsigned)(soff + q * 8 * p.K * 4), 0, 0);
                 }
             }
         };

@@ -39,7 +39,9 @@ __device__ __forceinline__ f32x4 lds_read16(int addr) { return *reinterpret_cast
 
 constexpr int PWH_WAVES = 8;
 constexpr int TBUF = 16 * 128;          // wave-private transpose buffer: 16 pixel rows x 32 channels fp32
-constexpr int RESQ = 3;                 // residual pieces in flight (epilogue steps ahead)
+// residual pieces in flight (epilogue steps ahead): the layers are HBM-bound and a wave's reads in flight are its only lever on the
+// memory pipe (8 waves per CU x 6-8 KB at ~2 us = ~6 TB/s chip-wide); bounded by the register file (256 per wave at 8 waves per CU)
+template <int MT> struct PwhCfg { static constexpr int RESQ = MT == 1 ? 5 : MT == 2 ? 4 : 2; };
 
 struct PwhArgs {
     const _Float16* x;     // [M, C1]
@@ -113,7 +115,9 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
     // A stream: (tile, k-step) pairs in order; loads run 4 k-steps ahead of the MFMAs, across tile boundaries.  The descriptor
     // of the tile being fetched covers exactly its rows (rows past M and tiles past the end of this wave's list have no records:
     // the loads stay unconditional and return zeros nobody uses)
-    f16x8 ring[4][MT];
+    // ring depth RD k-steps
+    constexpr int RD = 4;        // (8 for the one-row-tile form was tried: hipcc then spills ~56 registers per lane in every <1,8> instance)
+    f16x8 ring[RD][MT];
     int ld_tt = tt, ld_ks = 0;                   // position of the NEXT load of the stream
     __amdgpu_buffer_rsrc_t ld_rs1, ld_rs2;
     auto set_ld_tile = [&](int t) {
@@ -141,54 +145,73 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
         if (++ld_ks == nks) { ld_ks = 0; ld_tt += wstride; set_ld_tile(ld_tt); }
     };
 #pragma unroll
-    for (int s = 0; s < 4; ++s) issue_a(ring[s]);
+    for (int s = 0; s < RD; ++s) issue_a(ring[s]);
 
     f32x16 acc[MT][NT];
     f16x8 fb[NT];
-    int bj[NT];                                  // B fragment pointers: slab row (32 j + l & 31), k-slot (l >> 5), current trip
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        bj[j] = b_lane + j * 32 * LDW;
-        asm volatile("" : "+v"(bj[j]));
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj[j]));
+    int bj0 = b_lane;                            // B fragment pointer of n-tile 0: slab row (l & 31), k-slot (l >> 5), current trip; n-tile j
+    const int bstep = 32 * LDW;                  // sits bstep * j further (one v_add per read: nothing here is bound by the vector ALU)
 
-    // four k-steps (one trip around the A ring).  FIRST: the tile's first trip multiplies into the constant 0
-    auto trip = [&](int ks0, auto first_tag) {
+    // four k-steps (half / one trip around the A ring; `half` = ring slots 4 half .. 4 half + 3).  FIRST: the tile's first trip
+    // multiplies into the constant 0.  LAST: the tile's last trip does not fetch B fragments past its end -- the next tile reads its
+    // first ones itself, so that none are carried (32 registers) across the epilogue, where the residual ring needs them.
+    auto trip = [&](int ks0, auto half_tag, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int half = decltype(half_tag)::value;
+        const bool last = ks0 + 4 >= nks;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (u == 3) {
-                const int inc = ks0 + 4 < nks ? 128 : -(nks - 4) * 32;      // past the last k-step: back to step 0 (the next tile's first)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    bj[j] += inc;
-                    asm volatile("" : "+v"(bj[j]));
-                }
+                const int inc = !last ? 128 : -(nks - 4) * 32;      // past the last k-step: back to step 0 (the next tile's first)
+                bj0 += inc;
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
+                    const f16x8 av = ring[(4 * half + u) % RD][i];
                     if (FIRST && u == 0) {
                         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[u][i], fb[j], z, 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, fb[j], z, 0, 0, 0);
                     } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[u][i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, fb[j], acc[i][j], 0, 0, 0);
                     }
                 }
-                fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj[j] + (u < 3 ? (u + 1) * 32 : 0)));
+                if (!(last && u == 3)) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj0 + j * bstep + (u < 3 ? (u + 1) * 32 : 0)));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            issue_a(ring[u]);
+            issue_a(ring[(4 * half + u) % RD]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
+    int ph = 0;
     for (; tt < tiles_x; tt += wstride) {
-        trip(0, std::true_type{});
-        for (int ks0 = 4; ks0 < nks; ks0 += 4) trip(ks0, std::false_type{});
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj0 + j * bstep));
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
+        if constexpr (RD == 8) {
+            // the ring's phase: a tile of nks k-steps advances it by nks mod 8 (0 or 4) slots -- `ph` = the half its first trip reads
+            // (wave-uniform; the half is a compile-time constant of each trip: register sets are never selected at run time)
+            if (ph == 0) {
+                trip(0, H0{}, std::true_type{});
+                for (int ks0 = 4; ks0 < nks; ks0 += 8) {
+                    trip(ks0, H1{}, std::false_type{});
+                    if (ks0 + 4 < nks) trip(ks0 + 4, H0{}, std::false_type{});
+                }
+            } else {
+                trip(0, H1{}, std::true_type{});
+                for (int ks0 = 4; ks0 < nks; ks0 += 8) {
+                    trip(ks0, H0{}, std::false_type{});
+                    if (ks0 + 4 < nks) trip(ks0 + 4, H1{}, std::false_type{});
+                }
+            }
+            ph = (ph + (nks >> 2)) & 1;
+        } else {
+            trip(0, H0{}, std::true_type{});
+            for (int ks0 = 4; ks0 < nks; ks0 += 4) trip(ks0, H0{}, std::false_type{});
+        }
 
         // ---- epilogue: y = act(acc * scale + shift [+ residual]) -> fp16, through the wave-private transpose --------------
         // Steps s = (i, h, j) = half an MFMA tile each: 16 pixel rows x 32 channels; a lane finishes row (l >> 2), 8 channels at
@@ -200,6 +223,7 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
             (void*)((RES ? p.res : p.y) + (size_t)row0 * p.K), 0, ybytes, 0x00020000);
         constexpr int STEPS = MT * 2 * NT;
         auto soff_of = [&](int s) { return (16 * (s / NT) * p.K + n0 + 32 * (s % NT)) * 2; };      // wave-uniform byte offset of a step
+        constexpr int RESQ = PwhCfg<MT>::RESQ;
         u32x4 rv[RESQ];
         auto request = [&](int s) {
             if constexpr (RES) rv[s % RESQ] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, e_lane, soff_of(s), 0);
@@ -231,7 +255,11 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
                 f16x8 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { hv[e] = (_Float16)v0[e]; hv[e + 4] = (_Float16)v1[e]; }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, e_lane, soff_of(s), 0);
+                // (the step offset rides in the VECTOR offset: behind a 16-byte store with an SGPR offset hipcc puts the next step's
+                //  arithmetic without the wait state the store's data registers need -- the store then writes the NEXT step's values;
+                //  seen here as NaNs in the <2,4> residual form, in seam_pwpc.hip as wrong fourth channels.  tools/isa_store_hazard.py
+                //  scans the library's ISA for the pattern.)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, e_lane + (unsigned)soff_of(s), 0, 0);
             }
         };
         if (p.relu) steps(std::true_type{});
@@ -242,14 +270,18 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
 // 0 = not served by this kernel (the caller stays on the implicit GEMM); otherwise MT * 100 + NT
 inline int pwh_config(long long M, int C1, int C2, int K) {
     const int Ct = C1 + C2;
-    if (M <= 0 || M > 0x7fffffffLL / 64 || C1 <= 0 || (C1 % 64) || C2 < 0 || (C2 % 64) || Ct > 1024 || K <= 0 || (K % 64)) return 0;
+    // Ct <= 512: with the 64-channel slab a longer reduction needs (Ct = 1024) every A fragment feeds two MFMAs only and each input row
+    // is re-read by K / 64 slab groups -- the kernel is then bound by the L2, and measured 0.65x the implicit GEMM
+    // (profiles/r06_pwh_ab.txt: 1024 -> 256 at 48 x 84: 1274 vs 824 us).  Those layers stay on conv_igemm<_Float16,128,128>.
+    if (M <= 0 || M > 0x7fffffffLL / 64 || C1 <= 0 || (C1 % 64) || C2 < 0 || (C2 % 64) || Ct > 512 || K <= 0 || (K % 64)) return 0;
     const long room = 163840 - PWH_WAVES * TBUF;
     auto fits = [&](int ns) { return (long)ns * (Ct * 2 + 16) + 2L * ns * 4 <= room; };
     // (every branch needs its slab count K / NS to divide an XCD's 32 blocks: the block -> (slab, row group) decode walks the slabs
     //  inside each XCD's blocks)
     if (K % 256 == 0 && fits(256) && 32 % (K / 256) == 0) return 108;
     if (K % 128 == 0 && fits(128) && 32 % (K / 128) == 0) return 204;
-    if (fits(64) && 32 % (K / 64) == 0) return 402;
+    // 64-channel slabs (K not a multiple of 128): short reductions only -- 256 -> 64 measured 0.90x the implicit GEMM, 64 -> 64 1.21x
+    if (Ct <= 128 && fits(64) && 32 % (K / 64) == 0) return 402;
     return 0;
 }
 
@@ -258,7 +290,8 @@ inline int pwh_config(long long M, int C1, int C2, int K) {
 extern "C" {
 
 // MT * 100 + NT of the wave tile seam_conv1x1_swh_f16 will use for [M, C1 + C2] x [K, C1 + C2]^T, or 0 when the shape is not served
-// (C1 / C2 not multiples of 64, C1 + C2 > 1024, K not a multiple of 64 or a slab count that does not divide 32).  Independent of M.
+// (C1 / C2 not multiples of 64, C1 + C2 > 512 -- > 128 when K is not a multiple of 128 --, K not a multiple of 64 or a slab count that
+// does not divide 32).  Independent of M.
 int seam_conv1x1_swh_config(long long M, int C1, int C2, int K) { return pwh_config(M, C1, C2, K); }
 
 int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const float* scale, const float* shift, const void* residual,

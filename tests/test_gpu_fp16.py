@@ -312,10 +312,10 @@ def test_stem_space_to_depth_f16(ops, hw):
 
 
 @pytest.mark.parametrize("case", [
-    # n, C, H, W, K, relu, bn, residual        wave tiles <1,8> (C <= 256, K % 256 == 0), <2,4> (C <= 512, K % 128 == 0), <4,2> (C <= 1024)
+    # n, C, H, W, K, relu, bn, residual        wave tiles <1,8> (C <= 256, K % 256 == 0), <2,4> (C <= 512, K % 128 == 0), <4,2> (C <= 128)
     (3, 64, 41, 53, 256, True, True, True), (2, 256, 33, 31, 1024, True, True, True), (2, 256, 48, 72, 256, True, False, False),
     (2, 128, 40, 56, 512, False, True, False), (3, 512, 25, 42, 128, True, True, False), (2, 512, 24, 42, 256, True, False, True),
-    (2, 1024, 24, 42, 256, True, True, False), (1, 1024, 15, 17, 512, False, False, True), (2, 256, 20, 20, 64, True, True, False),
+    (2, 384, 24, 42, 256, True, True, False), (1, 512, 15, 17, 512, False, False, True), (2, 128, 20, 20, 64, True, True, True),
     (5, 64, 14, 14, 64, True, False, False), (1, 64, 200, 301, 256, True, True, True),
 ])
 def test_pointwise_streaming_kernel_f16(ops, case):
@@ -369,7 +369,7 @@ def test_pointwise_streaming_kernel_f16(ops, case):
 
 def test_pointwise_streaming_kernel_f16_dual_and_unserved(ops):
     """The two-source form (stride-1 projection shortcut: [W_a | W_b] . [h ; x]) on the streaming kernel == the implicit GEMM's dual
-    form to rounding; unserved shapes (C not a multiple of 64, C > 1024, K / slab not dividing 32) are refused by the C ABI and stay
+    form to rounding; unserved shapes (C not a multiple of 64, C > 512, 64-channel slabs with C > 128, K / slab not dividing 32) are refused by the C ABI and stay
     on the implicit GEMM in ops.conv2d."""
     import seam_match_rcnn_amd._native as native
     d = dev()
@@ -400,7 +400,7 @@ def test_pointwise_streaming_kernel_f16_dual_and_unserved(ops):
                  + ((b1[1] - b1[2] * s1) + (b2[1] - b2[2] * s2))[None, :, None, None])
     assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=4e-3, atol_scale=2e-3)
     dummy = torch.zeros(1 << 16, dtype=H, device=d)
-    for (c, kk) in [(96, 256), (2048, 256), (32, 64), (64, 96), (64, 8448 * 2)]:
+    for (c, kk) in [(96, 256), (1024, 256), (256, 64), (32, 64), (64, 96), (64, 8448 * 2)]:
         assert lib.seam_conv1x1_swh_config(1000, c, 0, kk) == 0
         assert lib.seam_conv1x1_swh_f16(dummy.data_ptr(), None, dummy.data_ptr(), None, None, None, dummy.data_ptr(), 64, c, 0, kk, 0,
                                         torch.cuda.current_stream().cuda_stream) != 0

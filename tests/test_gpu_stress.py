@@ -441,7 +441,7 @@ def stress_swh(rng):
         refs.append(("implicit GEMM (fp16)", yi))
         check("conv1x1_swh", desc, outs[0], outs[1], refs, 2e-3)
     dummy = torch.zeros(1 << 16, dtype=torch.float16, device=dev)
-    for (c, k) in [(96, 256), (2048, 256), (32, 64), (64, 96), (1088, 64)]:
+    for (c, k) in [(96, 256), (1024, 256), (32, 64), (64, 96), (576, 128), (256, 64)]:
         if lib.seam_conv1x1_swh_f16(P(dummy), None, P(dummy), None, None, None, P(dummy), 64, c, 0, k, 0, st()) == 0:
             fails.append(("conv1x1_swh", f"c={c} k={k}", "unserved channel count was not refused"))
     say(f"SUMMARY conv1x1_swh cases {done} seconds {time.time() - t0:.1f}")
