@@ -381,8 +381,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
                     }
                     SB();
 #if !(SEAM_F16PC_ABL & 2)
-                    load_b(st % RB, min(t * 36 + st + RB, n * 36 - 1));  // (past the tile's end: its last step again, never used -- the scalar
-                                                                         // offset takes no part in the descriptor's range check)
+                    load_b(st % RB, min(t * 36 + st + RB, n * 36 - 1));  // (past the tile's end: its last step again, never used)
 #endif
                 }
                 SB();

@@ -269,12 +269,16 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw_sw_kernel(const PwArgs p)
                             v[e] = o;
                         }
                     }
-                    // (the step offset rides in the VECTOR offset -- round 6: behind a 16-byte store with an SGPR offset hipcc places
-                    //  the next piece's arithmetic without the wait state the store's data registers need; tools/isa_store_hazard.py
-                    //  found `buffer_store_dwordx4 v[0:3], ..., s64 offen` / `v_pk_add_f32 v[2:3], ...` back to back in eight instances
-                    //  of this kernel.  No test ever saw a wrong value from it -- the s_waitcnt between the two happened to cover the
-                    //  read -- but seam_pwpc.hip (round 5) and seam_pwh.hip (round 6) did.)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, e_lane + (unsigned)(soff + q * 8 * p.K * 4), 0, 0);
+                    const u32x4 vbits = __builtin_bit_cast(u32x4, v);
+                    __builtin_amdgcn_raw_buffer_store_b128(vbits, y_rsrc, e_lane, soff + q * 8 * p.K * 4, 0);
+                    // Round 6: a 16-byte store reads its data registers over several cycles; behind one with an SGPR offset hipcc 7.2
+                    // places the next piece's arithmetic without a wait state (LLVM's hazard table assumes the hazard only exists for an
+                    // immediate scalar offset -- on gfx950 it does not hold: seam_pwpc.hip round 5 stored wrong fourth channels,
+                    // seam_pwh.hip round 6 NaNs).  tools/isa_store_hazard.py found `buffer_store_dwordx4 v[0:3], .., s64 offen` /
+                    // `v_pk_add_f32 v[2:3], ..` back to back in eight instances of this kernel; no test ever saw a wrong value (the
+                    // s_waitcnt between the two happened to cover the read), but nothing guaranteed it.  The data registers are an
+                    // input of the s_nop below: nothing may overwrite them before it has issued.
+                    asm volatile("s_nop 1" ::"v"(vbits));
                 }
             }
         };

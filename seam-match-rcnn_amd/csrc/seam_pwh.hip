@@ -119,6 +119,8 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
     constexpr int RD = 4;        // (8 for the one-row-tile form was tried: hipcc then spills ~56 registers per lane in every <1,8> instance)
     f16x8 ring[RD][MT];
     int ld_tt = tt, ld_ks = 0;                   // position of the NEXT load of the stream
+    // (gfx950 range-checks vector offset + scalar offset + immediate against the descriptor's size -- tools/probes/soffset_probe.hip,
+    //  profiles/r06_soffset_probe.txt -- so the row-group step may ride in the scalar offset: rows past M read as zeros)
     __amdgpu_buffer_rsrc_t ld_rs1, ld_rs2;
     auto set_ld_tile = [&](int t) {
         const int row0 = (xcd + 8 * t) * (32 * MT);
@@ -256,9 +258,9 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { hv[e] = (_Float16)v0[e]; hv[e + 4] = (_Float16)v1[e]; }
                 // (the step offset rides in the VECTOR offset: behind a 16-byte store with an SGPR offset hipcc puts the next step's
-                //  arithmetic without the wait state the store's data registers need -- the store then writes the NEXT step's values;
-                //  seen here as NaNs in the <2,4> residual form, in seam_pwpc.hip as wrong fourth channels.  tools/isa_store_hazard.py
-                //  scans the library's ISA for the pattern.)
+                //  arithmetic without the wait state the store's data registers need -- LLVM's hazard table only covers an immediate
+                //  scalar offset -- and the store then writes the NEXT step's values: seen here as NaNs in the <2,4> residual form, in
+                //  seam_pwpc.hip as wrong fourth channels.  tools/isa_store_hazard.py scans the library's ISA for the pattern.)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, e_lane + (unsigned)soff_of(s), 0, 0);
             }
         };

@@ -247,8 +247,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pc(const PwpcArgs p) {
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            // (the row step rides in the VECTOR offset: the descriptor's range check covers vector offset + immediate only, a
-                            //  scalar offset is added unchecked -- on a ragged last tile the rows past `rows` must fall outside and read zero)
+                            // (row step in the vector offset, like the stores; either form is range-checked on gfx950 -- vector + scalar +
+                            //  immediate against the descriptor's size, profiles/r06_soffset_probe.txt: rows past `rows` read zero)
                             rv[m][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, ocol + m * K32 + i * K8, 0, 0));
                 }
                 const int nbuf = cbuf == NBUF - 1 ? 0 : cbuf + 1;

@@ -261,9 +261,9 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     constexpr int NRS = NT == 1 ? 2 : 1;     // register sets of the raw patch: prefetch distance 2 chunks / 1 (twice as long) chunk
     f32x4 rset[NRS][NI];
     auto load_raw = [&](f32x4 (&rs)[NI], int chunk) {
-        // chunks past the end (the prefetch runs 2-4 ahead) re-read the last chunk and are never used.  (Clamped, one s_min: the
-        // chunk offset rides in the SCALAR offset, which the descriptor's range check does not cover -- unclamped, the last
-        // pixel of the image group would read up to 128 bytes past x.)
+        // chunks past the end (the prefetch runs 2-4 ahead) re-read the last chunk and are never used (one s_min; unclamped they
+        // would read the next pixel's channels or, at the image group's last pixel, fall outside the descriptor and read zeros:
+        // gfx950 range-checks the scalar offset too, profiles/r06_soffset_probe.txt)
         const int so = min(chunk, p.nchunks - 1) * 32;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -279,8 +279,7 @@ __device__ __forceinline__ void w24_block(const Wino24Args& p, char* smem, const
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.u + (size_t)tn * NT * ntile_bytes), 0, NT * ntile_bytes, 0x00020000);
     // lane offsets of positions nu = 0..3 and 4..5: the per-position 1 KiB steps then fit the instruction's 12-bit immediate, and the
-    // scalar offset is one value per chunk (and n-tile).  Chunks past the end are clamped to the last one (the scalar offset is not
-    // range-checked by the descriptor: unclamped, the last n-tile would read one chunk past the packed weights) and never used.
+    // scalar offset is one value per chunk (and n-tile).  Chunks past the end are clamped to the last one and never used.
     // (ONE lane offset, made opaque once per chunk: hipcc otherwise hoists the six "offset + nu KiB" sums out of the K loop, parks
     //  them in AccVGPRs and pays a v_accvgpr_read -- a vector-ALU instruction, i.e. ~20 idle cycles of the fp32 matrix pipe -- per load)
     int uoff0 = (xi * 6 * 64 + lane) * 16;
@@ -974,7 +973,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         f32x4 rq[2][NP];                        // the pieces of two groups (group parity)
         f32x4 xa[3], xb[3], ya[3], yb[3], va[6];
         auto load_group = [&](f32x4 (&dst)[NP]) {      // request group gL of the load stage's tile
-            const int so = min(gL, (n >> 2) - 1) * 128;     // (never past a tile's last group: the scalar offset is not range-checked)
+            const int so = min(gL, (n >> 2) - 1) * 128;     // (never past a tile's last group)
 #pragma unroll
             for (int r = 0; r < NP; ++r)
                 dst[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcL, goff[r], so, 0));
@@ -1170,7 +1169,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
         for (int k = 0; k < ntiles; ++k) {
             const PcGeo q = pc_geo(p, tile);
             auto load_b = [&](int slot_, int nu, int chunk) {
-                const int so = min(chunk, n - 1) * 24576 + (nu >> 2) * 4096;     // (clamped: the scalar offset is not range-checked)
+                const int so = min(chunk, n - 1) * 24576 + (nu >> 2) * 4096;     // (chunks past the end: the last one again)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     bq[slot_][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff0 + (nu & 3) * 1024, so + nt * ntile_bytes, 0));

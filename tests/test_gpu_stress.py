@@ -113,7 +113,9 @@ def torch_conv3x3(x, wt, pad):
 def check(name, desc, got, got2, refs, tol):
     ok = True
     why = ""
-    if not torch.equal(got, got2):
+    if not guards_intact():
+        ok, why = False, "bytes BEHIND the output tensor were overwritten"
+    elif not torch.equal(got, got2):
         ok, why = False, "two launches differ"
     elif not bool(torch.isfinite(got.float()).all()):
         ok, why = False, "poison / non-finite values left in the output"
@@ -130,8 +132,30 @@ def check(name, desc, got, got2, refs, tol):
     return ok
 
 
+GUARD = 1 << 20          # bytes behind every output that must stay untouched (a ragged last tile must not write past the tensor)
+_guards = []
+
+
 def poisoned(shape, dtype, which):
-    return torch.full(shape, float("nan") if which == 0 else 3.0e4, dtype=dtype, device=dev)
+    """An output tensor filled with poison, carved out of a larger allocation whose tail (GUARD bytes of 0x5A) is checked by
+    guards_intact(): a kernel that computes a ragged last tile's addresses wrongly (or trusts a range check that does not cover
+    them) writes past the tensor -- into whatever the allocator placed behind it."""
+    n = 1
+    for d in shape:
+        n *= d
+    es = torch.empty((), dtype=dtype).element_size()
+    raw = torch.empty(n * es + GUARD, dtype=torch.uint8, device=dev)
+    raw[n * es:].fill_(0x5A)
+    y = raw[:n * es].view(dtype).view(shape)
+    y.fill_(float("nan") if which == 0 else 3.0e4)
+    _guards.append(raw[n * es:])
+    return y
+
+
+def guards_intact():
+    ok = all(bool((g == 0x5A).all()) for g in _guards)
+    _guards.clear()
+    return ok
 
 
 # ------------------------------------------------------------------------------------------------ conv3x3_wino24pc
