@@ -667,8 +667,8 @@ def roofline_leg(step, dtype):
     if dtype == "f16":
         # frac stays against the nominal dense peak; what the chip sustains on this instruction is measured separately
         extra["sustained_mfma_tflops_measured"] = {
-            "dense_random_operands": 1760.0, "zero_operands": 2492.0,
-            "source": "profiles/r05_mfma_clock_trace.txt: bare v_mfma_f32_32x32x16_f16 on every SIMD, operands in registers -- "
+            "dense_random_operands": 1760.0, "zero_operands": 2492.0, "measured_in_this_run": False,
+            "source": "profiles/r05_mfma_clock_trace.txt (a committed probe trace of an earlier round, quoted -- not re-measured here): bare v_mfma_f32_32x32x16_f16 on every SIMD, operands in registers -- "
                       "the 1300 W package limit holds the clock at 1.72 GHz on dense random operands (2.40 GHz / 842 W on zeros)"}
     return {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), **extra,

@@ -321,6 +321,13 @@ int seam_rank_topk_f32(const float* logits, int64_t* idx, float* score, int Q, i
  * product target[q] in the descending ranking of query q (what `(rankings == shop_prod_index)
  * .nonzero()` extracts at evaluate_movingfashion.py:228,268), same tie rule as seam_rank_topk_f32. */
 int seam_match_scores_f32(const float* logits, float* score, int64_t n_pairs, seam_stream_t stream);
+/* Block-diagonal self-similarity for the evaluator's tracking step (`compute_selfdist` once per product,
+ * evaluate_movingfashion.py:102-121,165-176) in ONE launch: x [rows, Dd] holds the detections' descriptors grouped by product,
+ * seg int32 [n_seg + 1] the group boundaries (row offsets), out_off int64 [n_seg + 1] the running sum of n_s^2; for every group
+ * out[out_off[s] + i * n_s + j] = softmax(W (x_i - x_j)^2 + b)[1].  Only the n_s x n_s diagonal blocks are computed (the all-pairs
+ * matrix of a pass is rows^2).  max_rows >= every n_s.  Bit-identical to seam_pair_logits_f32 + seam_match_scores_f32 per group. */
+int seam_pair_scores_blockdiag_f32(const float* x, const int* seg, const int64_t* out_off, const float* w, const float* bias,
+                                   float* out, int n_seg, int max_rows, int Dd, seam_stream_t stream);
 int seam_rank_of_f32(const float* logits, const int64_t* target, int64_t* rank, int Q, int G,
                      seam_stream_t stream);
 

@@ -556,6 +556,45 @@ __global__ __launch_bounds__(256) void pair_logits_kernel(const float* __restric
     }
 }
 
+// Block-diagonal self-similarity (evaluator tracking, ref evaluate_movingfashion.py:165-176 `compute_selfdist` per product): for every
+// segment s of rows [seg[s], seg[s+1]) of x, score[out_off[s] + i * n + j] = softmax(W (x_i - x_j)^2 + b)[1] for all pairs INSIDE the
+// segment -- the n_s x n_s diagonal blocks of the all-pairs matrix only, in one launch.  Same tile, FMA order, bias add and softmax
+// expression as pair_logits_kernel<2,2> + match_scores_kernel: bit-identical to computing each block on its own.
+// grid (max tiles of a segment, segments); blocks past a segment's tile count exit.
+__global__ __launch_bounds__(256) void pair_scores_blockdiag_kernel(const float* __restrict__ x, const int* __restrict__ seg,
+                                                                    const int64_t* __restrict__ out_off, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, float* __restrict__ out, int Dd) {
+    constexpr int QT = 2, GT = 2, BQ = 8 * QT, BG = 32 * GT;
+    __shared__ __attribute__((aligned(16))) PairLds<QT, GT> L;
+    const int s = blockIdx.y;
+    const int r0 = seg[s], n = seg[s + 1] - r0;
+    const int tg_n = (n + BG - 1) / BG, tq_n = (n + BQ - 1) / BQ;
+    if ((int)blockIdx.x >= tg_n * tq_n) return;
+    const int tq = blockIdx.x / tg_n, tg = blockIdx.x - tq * tg_n;
+    const int tid = threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
+    const int q0 = tq * BQ, g0 = tg * BG;
+    const float* xs = x + (size_t)r0 * Dd;
+    f32x2 acc[QT][GT];
+    pair_tile<QT, GT>(xs, xs, w, q0, g0, n, n, Dd, L, acc);
+    const f32x2 bz = {bias[0], bias[1]};
+    float* o = out + out_off[s];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+        const int qi = q0 + ty * QT + i;
+        if (qi >= n) continue;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+            const int gj = g0 + tx + 32 * j;
+            if (gj >= n) continue;
+            const f32x2 lg = acc[i][j] + bz;
+            const float mx = fmaxf(lg.x, lg.y);
+            const float e0 = expf(lg.x - mx), e1 = expf(lg.y - mx);
+            o[(size_t)qi * n + gj] = e1 / (e0 + e1);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void rank_topk_kernel(const float* __restrict__ logits, int64_t* __restrict__ idx,
                                                         float* __restrict__ score, int G, int k) {
     __shared__ TopkShared sh;
@@ -786,6 +825,16 @@ int seam_pair_logits_f32(const float* a, const float* b, const float* w, const f
         hipLaunchKernelGGL((pair_logits_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, b, w, bias, out,
                            Q, G, Dd);
     }
+    return (int)hipGetLastError();
+}
+
+int seam_pair_scores_blockdiag_f32(const float* x, const int* seg, const int64_t* out_off, const float* w, const float* bias,
+                                   float* out, int n_seg, int max_rows, int Dd, void* stream) {
+    if (n_seg <= 0 || max_rows <= 0) return 0;
+    if (Dd % 32 || n_seg > 65535) return (int)hipErrorInvalidValue;
+    const int tiles = ((max_rows + 63) / 64) * ((max_rows + 15) / 16);
+    hipLaunchKernelGGL(pair_scores_blockdiag_kernel, dim3((unsigned)tiles, (unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, x, seg,
+                       out_off, w, bias, out, Dd);
     return (int)hipGetLastError();
 }
 

@@ -248,6 +248,8 @@ def evaluate_tables(t: DescriptorTables, temporal_aggregator, k_thresholds: Sequ
         if p not in first_shop:
             continue
         lo, hi = np.searchsorted(sp_sorted, p, "left"), np.searchsorted(sp_sorted, p, "right")
+        if hi == lo:        # before any device work; the reference fails here too (np.stack of an empty list, evaluate_movingfashion.py:211)
+            raise ValueError(f"evaluate: product {p} has no street detections (the model's empty-image fallback box normally prevents this)")
         todo.append((p, first_shop[p], order[lo:hi]))
 
     def idx(a):
@@ -267,12 +269,9 @@ def evaluate_tables(t: DescriptorTables, temporal_aggregator, k_thresholds: Sequ
         dets_d = idx(dets_all)
         mine_all = t.street_mat[dets_d]
 
-        # ---- tracking (:166-214): all-pairs similarity of the pass's detections, its diagonal blocks to the host (copy 1)
-        sim_full = ops.match_scores(ops.pair_logits(mine_all, mine_all, t.w, t.b))
-        flat = np.concatenate([((o + np.arange(n))[:, None] * ndet + (o + np.arange(n))[None, :]).reshape(-1)
-                               for o, n in zip(offs[:-1], np.diff(offs))]) if ndet else np.zeros((0,), dtype=np.int64)
-        blocks = sim_full.view(-1)[idx(flat)].cpu().numpy()
-        del sim_full
+        # ---- tracking (:166-214): self-similarity of every product's detections -- the diagonal blocks only, one launch
+        # (round 6; the all-pairs matrix of a pass is ndet^2 = up to 2048^2 pairs for sum n_i^2 useful ones) -- to the host (copy 1)
+        blocks = ops.pair_scores_blockdiag(mine_all.contiguous(), offs, t.w, t.b).cpu().numpy()
         tracks_all, bo = [], 0
         for (p, _, dets), o in zip(batch, offs[:-1]):
             n = len(dets)

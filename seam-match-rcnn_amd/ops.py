@@ -912,6 +912,29 @@ def match_scores(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pair_scores_blockdiag(x: torch.Tensor, seg, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """Self-similarity of every group of rows of ``x`` [rows, D] (groups = consecutive row ranges, boundaries ``seg`` [n_seg + 1]):
+    the flat concatenation of the n_s x n_s score blocks, softmax(W (x_i - x_j)^2 + b)[1].  One launch for all groups
+    (``seam_pair_scores_blockdiag_f32``); bit-identical to ``match_scores(pair_logits(x_s, x_s))`` per group
+    (ref evaluate_movingfashion.py:102-121 ``compute_selfdist``)."""
+    import numpy as np
+    x = _req(x, name="x")
+    seg = np.asarray(seg, dtype=np.int64)
+    n = np.diff(seg)
+    if len(n) == 0 or int(n.max()) == 0:
+        return torch.empty((0,), dtype=F32, device=x.device)
+    if seg[0] != 0 or int(seg[-1]) > x.shape[0] or (n < 0).any():
+        raise ValueError("pair_scores_blockdiag: seg must be non-decreasing row offsets inside x, starting at 0")
+    off = np.concatenate([[0], np.cumsum(n * n)])
+    out = torch.empty((int(off[-1]),), dtype=F32, device=x.device)
+    seg_d = torch.as_tensor(seg, dtype=torch.int32, device=x.device)
+    off_d = torch.as_tensor(off, dtype=torch.int64, device=x.device)
+    _native.check(_native.lib().seam_pair_scores_blockdiag_f32(_ptr(x), _ptr(seg_d), _ptr(off_d), _ptr(_req(w, name="w")), _ptr(_req(bias, name="bias")),
+                                                               _ptr(out), len(n), int(n.max()), x.shape[1], _stream()),
+                  "seam_pair_scores_blockdiag_f32")
+    return out
+
+
 def rank_of(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """logits [Q,G,2], target int64 [Q] -> rank int64 [Q] of the target product in each query's ranking."""
     logits, target = _req(logits), _req(target, torch.int64, "target")

@@ -249,6 +249,80 @@ def test_batched_tables_equal_the_per_product_form(max_dets):
 
 
 @pytest.mark.gpu
+def test_batched_tables_equal_the_per_product_form_at_scale():
+    """ADVICE r4 / VERDICT r5 item 7: the batched evaluator at a realistic size -- 320 products x 10 frames (3200 street boxes,
+    ragged detections per product), 20 000 shop entries -- produces the SAME report as the per-product form (the round-2 code,
+    one product at a time); the tracking step computes the products' diagonal self-similarity blocks in one launch
+    (seam_pair_scores_blockdiag_f32) instead of the pass's all-pairs matrix."""
+    from seam_match_rcnn_amd import evaluator as EV
+    from seam_match_rcnn_amd.models.match_head import TemporalAggregationNLB
+    dev = torch.device("cuda:0")
+    tab = make_tables(11, n_products=320, n_shop=20000, frames=10, noise=0.8)
+    agg_sd = to_torch(synth.temporal_aggregator_state(12))
+    ta = TemporalAggregationNLB()
+    ta.load_state_dict(agg_sd)
+    ta = ta.to(dev).eval()
+    d = lambda k: torch.from_numpy(tab[k]).to(dev)      # noqa: E731
+    t = EV.DescriptorTables(shop_mat=d("shop_mat"), shop_aggr=d("shop_aggr"), shop_prods=tab["shop_prods"], shop_sources=tab["shop_sources"],
+                            street_mat=d("street_mat"), street_aggr=d("street_aggr"), street_prods=tab["street_prods"],
+                            street_imgs=tab["street_imgs"], street_scores=tab["street_scores"], street_boxes=d("street_boxes"),
+                            tracklets_gt=d("tracklets_gt"), w=d("w"), b=d("b"), count_street=tab["count_street"])
+    a = EV.evaluate_tables(t, ta, frames_per_product=10)
+    b = EV.evaluate_tables_per_product(t, ta, frames_per_product=10)
+    assert a.track_lens == b.track_lens and a.frame_ranks == b.frame_ranks
+    assert (a.count_reg, a.count_hard) == (b.count_reg, b.count_hard) and a.count_reg + a.count_hard == 320
+    for k in a.counts:
+        assert (a.counts[k] == b.counts[k]).all(), k
+    for k in a.per_product:
+        for kk in ("sfmr", "seamrcnn"):
+            assert (a.per_product[k][kk] == b.per_product[k][kk]).all()
+    assert a.tables_text() == b.tables_text()
+
+
+@pytest.mark.gpu
+def test_blockdiag_self_similarity_is_the_per_group_form_bit_for_bit():
+    """seam_pair_scores_blockdiag_f32 == match_scores(pair_logits(x_s, x_s)) for every group: ragged groups from 1 to 150 rows
+    (several 16 x 64 tiles), an empty group in the middle; and a product without street detections is refused up front."""
+    from seam_match_rcnn_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    sizes = [1, 7, 0, 16, 17, 64, 65, 150, 3]
+    seg = np.concatenate([[0], np.cumsum(sizes)])
+    x = torch.from_numpy(rng.standard_normal((int(seg[-1]), 256)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((2, 256)) * 0.05).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.standard_normal(2).astype(np.float32)).to(dev)
+    got = ops.pair_scores_blockdiag(x, seg, w, b)
+    assert got.numel() == sum(n * n for n in sizes)
+    o = 0
+    for s0, n in zip(seg[:-1], sizes):
+        if n:
+            xs = x[s0:s0 + n].contiguous()
+            assert torch.equal(got[o:o + n * n].view(n, n), ops.match_scores(ops.pair_logits(xs, xs, w, b))), n
+        o += n * n
+
+
+def test_product_without_street_detections_is_refused_before_device_work():
+    """(CPU) the batched evaluator names a product that has a shop entry but no street detection -- before any launch; the
+    reference fails at the same place (np.stack of an empty list, evaluate_movingfashion.py:211)."""
+    from seam_match_rcnn_amd import evaluator as EV
+    tab = make_tables(3, n_products=4, n_shop=8, frames=2)
+    keep = tab["street_prods"] != 2
+    t = EV.DescriptorTables(shop_mat=torch.from_numpy(tab["shop_mat"]), shop_aggr=torch.from_numpy(tab["shop_aggr"]), shop_prods=tab["shop_prods"],
+                            shop_sources=tab["shop_sources"], street_mat=torch.from_numpy(tab["street_mat"][keep]),
+                            street_aggr=torch.from_numpy(tab["street_aggr"][keep]), street_prods=tab["street_prods"][keep],
+                            street_imgs=tab["street_imgs"][keep], street_scores=tab["street_scores"][keep],
+                            street_boxes=torch.from_numpy(tab["street_boxes"][keep]), tracklets_gt=torch.from_numpy(tab["tracklets_gt"]),
+                            w=torch.from_numpy(tab["w"]), b=torch.from_numpy(tab["b"]), count_street=tab["count_street"])
+
+    class _TA:      # never reached
+        class last:
+            weight = torch.zeros(2, 256)
+            bias = torch.zeros(2)
+    with pytest.raises(ValueError, match="product 2 has no street detections"):
+        EV.evaluate_tables(t, _TA())
+
+
+@pytest.mark.gpu
 def test_score_reduce_segments_equals_per_segment_calls():
     from seam_match_rcnn_amd import ops
     dev = torch.device("cuda:0")

@@ -18,7 +18,7 @@ for k in agg:
     d=sum(dur[k])/len(dur[k])/1e3
     c={c: sum(v)/len(v) for c,v in agg[k].items()}
     extra=""
-    if "GRBM_GUI_ACTIVE" in c: extra+=" clock_GHz %.3f" % (c["GRBM_GUI_ACTIVE"]/d/1e3)
+    if "GRBM_GUI_ACTIVE" in c: extra+=" clock_GHz %.3f" % (c["GRBM_GUI_ACTIVE"]/8/d/1e3)      # (the counter sums the 8 XCDs)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CU_CYCLES" in c: extra+=" mfma_busy %.3f" % (c["SQ_VALU_MFMA_BUSY_CYCLES"]/(4*c["SQ_BUSY_CU_CYCLES"]))
     print("$S", k, "${SEAM_LIB_PATH##*/}", "PC=${SEAM_W24_PC:-1}", "dur_us %.1f" % d, extra, {a: round(b) for a,b in c.items()})
 PY
