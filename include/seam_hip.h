@@ -321,6 +321,15 @@ int seam_rank_topk_f32(const float* logits, int64_t* idx, float* score, int Q, i
  * product target[q] in the descending ranking of query q (what `(rankings == shop_prod_index)
  * .nonzero()` extracts at evaluate_movingfashion.py:228,268), same tie rule as seam_rank_topk_f32. */
 int seam_match_scores_f32(const float* logits, float* score, int64_t n_pairs, seam_stream_t stream);
+/* HOST helper (host pointers, no device work, no stream): the greedy tracklet linking of evaluate_movingfashion.py:166-202 for all
+ * products of an evaluator pass.  blocks = the products' n_s x n_s self-similarity blocks concatenated (what
+ * seam_pair_scores_blockdiag_f32 wrote, copied to the host); seg int64 [n_seg + 1] detection offsets; imgs int64 / scores double
+ * [seg[n_seg]] frame index / confidence per detection.  Out: members_out [seg[n_seg]] -- per product, at seg[s], the LOCAL detection
+ * indices tracklet after tracklet (creation order), members in link order; track_len_out [seg[n_seg]] -- at seg[s] the lengths of
+ * that product's tracklets; n_tracks_out [n_seg].  Same decisions as the reference's loops (first maximum in row-major order). */
+int seam_host_build_tracklets(const float* blocks, const int64_t* seg, const int64_t* imgs, const double* scores, int n_seg,
+                              double threshold, int32_t* members_out, int32_t* track_len_out, int32_t* n_tracks_out);
+
 /* Block-diagonal self-similarity for the evaluator's tracking step (`compute_selfdist` once per product,
  * evaluate_movingfashion.py:102-121,165-176) in ONE launch: x [rows, Dd] holds the detections' descriptors grouped by product,
  * seg int32 [n_seg + 1] the group boundaries (row offsets), out_off int64 [n_seg + 1] the running sum of n_s^2; for every group

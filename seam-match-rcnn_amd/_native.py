@@ -109,6 +109,7 @@ SIGNATURES = {
     "seam_pair_logits_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "seam_rank_topk_f32": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "seam_match_scores_f32": (_i, [_p, _p, _i64, _p]),
+    "seam_host_build_tracklets": (_i, [_p, _p, _p, _p, _i, C.c_double, _p, _p, _p]),
     "seam_pair_scores_blockdiag_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "seam_rank_of_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "seam_score_reduce_f32": (_i, [_p, _p, _i, _i, _i, _p]),

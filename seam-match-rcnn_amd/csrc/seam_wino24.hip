@@ -676,7 +676,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv3x3_wino24(const Win
 // The arithmetic (transform expressions, accumulation order, epilogue) is that of conv3x3_wino24<2>: results are bit-identical.
 // =====================================================================================================================
 #ifndef SEAM_W24PC_ABL
-#define SEAM_W24PC_ABL 0    // experiments: 1 no in-loop patch loads / stores (64: no stores only, 128: no requests only), 2 no in-loop weight loads, 8 no in-loop transforms, 16 no epilogue arithmetic
+#define SEAM_W24PC_ABL 0    // experiments: 1 no in-loop patch loads / stores (64: no stores only, 128: no requests only), 2 no in-loop weight loads, 8 no in-loop transforms, 16 no epilogue arithmetic,
+                            // 256 (round 6, TIMING ONLY -- results are garbage): the weight fragments travel through LDS -- the producers issue
+                            // them as LDS-DMA loads (buffer_load_dwordx4 ... lds) into the exchange region, the consumers read them with ds_read_b128
 #endif
 #ifndef SEAM_W24PC_RING
 #define SEAM_W24PC_RING 4
@@ -1100,6 +1102,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                     __builtin_amdgcn_s_sleep(SEAM_W24PC_PSLEEP);
 #endif
                     tr_write((j + 1) & 1);
+#if SEAM_W24PC_ABL & 256
+                    {       // this wave pair's twelve fragments of a chunk two ahead: global -> LDS, no registers (never waited for: timing only)
+                        const int nb = n * 24576;
+                        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
+                            (void*)((const char*)p.u + (size_t)pc_geo(p, tile).tn * NT * nb), 0, NT * nb, 0x00020000);
+                        const int ck = min(i0 + j + 2, n - 1) * 24576;
+#pragma unroll
+                        for (int r = 0; r < 12; ++r)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (LDSQ void*)((LDSQ char*)smem + PC_EX + (xi * 12 + r) * 1024), 16,
+                                                                     (xi * 6 * 64 + lane) * 16 + (r % 6 & 3) * 1024, ck + ((r % 6) >> 2) * 4096 + (r / 6) * nb, 0, 0);
+                    }
+#endif
 #ifdef SEAM_W24PC_PSLEEP
                     __builtin_amdgcn_s_sleep(SEAM_W24PC_PSLEEP);
 #endif
@@ -1172,7 +1186,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino24pc(const Wino24Args p) {
                 const int so = min(chunk, n - 1) * 24576 + (nu >> 2) * 4096;     // (chunks past the end: the last one again)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+#if SEAM_W24PC_ABL & 256
+                    (void)so;
+                    bq[slot_][nt] = *reinterpret_cast<const f32x4*>(smem + PC_EX + ((xi * 6 + nu) * 2 + nt) * 1024 + lane * 16);
+#else
                     bq[slot_][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uoff0 + (nu & 3) * 1024, so + nt * ntile_bytes, 0));
+#endif
                     SB();
                 }
             };

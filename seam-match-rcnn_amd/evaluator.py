@@ -114,29 +114,62 @@ def build_tracklets(simmat: np.ndarray, imgs: np.ndarray, scores: np.ndarray, th
     member; link it if that similarity exceeds ``threshold`` (it then closes its frame), else stop.
     Returns tracklets as lists of LOCAL detection indices, in creation order."""
     n = len(imgs)
+    imgs = np.asarray(imgs, dtype=np.int64)
     free = np.ones(n, dtype=bool)
-    all_frames = np.unique(imgs)
+    present = np.zeros(int(imgs.max()) + 1 if n else 0, dtype=bool)     # frames that have a detection at all
+    present[imgs] = True
     tracks: List[List[int]] = []
     while free.any():
         cand = np.flatnonzero(free)
         start = int(cand[np.argmax(scores[cand])])
         members = [start]
-        open_frames = set(int(f) for f in all_frames if f != imgs[start])
-        while open_frames:
+        open_f = present.copy()                     # frames without a member yet
+        open_f[imgs[start]] = False
+        while open_f.any():
             # `free` still holds the members of the tracklet under construction: they are only retired when it is
-            # closed, but their frames are closed, so they can never be picked again.
-            pool = np.asarray([j for j in range(n) if free[j] and int(imgs[j]) in open_frames], dtype=np.int64)
+            # closed, but their frames are closed, so they can never be picked again.  (Vectorised in round 6: the pool in
+            # ascending detection order and the row-major argmax pick the same element as the reference's Python loops.)
+            pool = np.flatnonzero(free & open_f[imgs])
             if pool.size == 0:
                 break
-            sub = simmat[np.sort(np.asarray(members))][:, pool]        # rows in detection order, like the reference
-            r, c = np.unravel_index(int(np.argmax(sub)), sub.shape)
+            rows = np.sort(np.asarray(members))     # rows in detection order, like the reference
+            sub = simmat[np.ix_(rows, pool)]
+            r, c = divmod(int(np.argmax(sub)), sub.shape[1])
             if not sub[r, c] > threshold:
                 break
             members.append(int(pool[c]))
-            open_frames -= {int(imgs[m]) for m in members}
+            open_f[imgs[members[-1]]] = False       # (the earlier members' frames are closed already)
         free[members] = False
         tracks.append(members)
     return tracks
+
+
+def build_tracklets_batch(blocks: np.ndarray, seg: np.ndarray, imgs_all: np.ndarray, scores_all: np.ndarray,
+                          threshold: float) -> List[List[List[int]]]:
+    """``build_tracklets`` for every product of a pass in ONE native call (``seam_host_build_tracklets``, csrc/seam_tracklets.hip;
+    host code): ``blocks`` = the products' self-similarity blocks concatenated, ``seg`` their detection offsets."""
+    from . import _native
+    seg = np.ascontiguousarray(seg, dtype=np.int64)
+    n_seg, ndet = len(seg) - 1, int(seg[-1])
+    blocks = np.ascontiguousarray(blocks, dtype=np.float32)
+    imgs_all = np.ascontiguousarray(imgs_all, dtype=np.int64)
+    scores_all = np.ascontiguousarray(scores_all, dtype=np.float64)
+    members = np.empty(max(ndet, 1), dtype=np.int32)
+    lens = np.empty(max(ndet, 1), dtype=np.int32)
+    ntr = np.empty(max(n_seg, 1), dtype=np.int32)
+    rc = _native.lib().seam_host_build_tracklets(blocks.ctypes.data, seg.ctypes.data, imgs_all.ctypes.data, scores_all.ctypes.data, n_seg,
+                                                 float(threshold), members.ctypes.data, lens.ctypes.data, ntr.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"seam_host_build_tracklets failed: {rc}")
+    out = []
+    for s in range(n_seg):
+        o, tracks, mo = int(seg[s]), [], 0
+        for k in range(int(ntr[s])):
+            ln = int(lens[o + k])
+            tracks.append(members[o + mo:o + mo + ln].tolist())
+            mo += ln
+        out.append(tracks)
+    return out
 
 
 @dataclass
@@ -272,12 +305,7 @@ def evaluate_tables(t: DescriptorTables, temporal_aggregator, k_thresholds: Sequ
         # ---- tracking (:166-214): self-similarity of every product's detections -- the diagonal blocks only, one launch
         # (round 6; the all-pairs matrix of a pass is ndet^2 = up to 2048^2 pairs for sum n_i^2 useful ones) -- to the host (copy 1)
         blocks = ops.pair_scores_blockdiag(mine_all.contiguous(), offs, t.w, t.b).cpu().numpy()
-        tracks_all, bo = [], 0
-        for (p, _, dets), o in zip(batch, offs[:-1]):
-            n = len(dets)
-            simmat = blocks[bo:bo + n * n].reshape(n, n)
-            bo += n * n
-            tracks_all.append(build_tracklets(simmat, t.street_imgs[dets], t.street_scores[dets], tracking_threshold))
+        tracks_all = build_tracklets_batch(blocks, offs, t.street_imgs[dets_all], t.street_scores[dets_all], tracking_threshold)
         # IoU of every tracklet member with the ground truth of every member's frame (copy 2); the reference indexes the GT list
         # by the frame index inside the clip (:205)
         imgs_all = t.street_imgs[dets_all]

@@ -157,6 +157,34 @@ def test_tracklet_builder_matches_oracle_lists():
             assert len(set(imgs[t])) == len(t)                                 # one detection per frame
 
 
+def test_native_tracklet_builder_equals_the_python_form():
+    """seam_host_build_tracklets (host C++ in the library, all products of a pass in one call) takes the same decisions as
+    ``build_tracklets`` (the element-for-element restatement of evaluate_movingfashion.py:166-202 pinned above): 600 random
+    products with ragged frames, tied similarities and tied confidences, both thresholds."""
+    from seam_match_rcnn_amd import evaluator as EV
+    rng = np.random.default_rng(42)
+    for thr in (0.3, 0.7):
+        seg, blocks, imgs_all, sc_all, want = [0], [], [], [], []
+        for trial in range(300):
+            imgs = []
+            for f in range(10):
+                if trial % 7 == 3 and f == 1:
+                    continue
+                imgs += [f] * (1 + int(rng.integers(0, 3)))
+            imgs = np.asarray(imgs)
+            n = len(imgs)
+            sim = rng.uniform(0, 1, (n, n)).astype(np.float32)
+            sc = rng.uniform(0, 1, n).astype(np.float32)
+            if trial % 5 == 0:
+                sim = np.round(sim, 1)
+            if trial % 3 == 0:
+                sc = np.round(sc, 1)
+            want.append(EV.build_tracklets(sim, imgs, sc, thr))
+            blocks.append(sim.reshape(-1)); imgs_all.append(imgs); sc_all.append(sc); seg.append(seg[-1] + n)
+        got = EV.build_tracklets_batch(np.concatenate(blocks), np.asarray(seg), np.concatenate(imgs_all), np.concatenate(sc_all), thr)
+        assert got == want
+
+
 def test_tracklet_builder_known_answer():
     from seam_match_rcnn_amd.evaluator import build_tracklets
     # frames 0,0,1,2: det0 (score .9) seeds; det2 (frame 1) links via sim .8; det3 (frame 2) only reaches .2 -> new track
