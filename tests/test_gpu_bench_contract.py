@@ -55,7 +55,9 @@ def test_bench_line_and_roofline_fields():
     # the timed step's outputs are checked against the oracle's inside the bench run itself
     p = d["parity"]
     assert p["checked"] is True and p["ok"] is True and p["max_err_of_scale"] <= 1e-3 and p["topk_set_overlap"] >= 0.99
-    assert set(p["err_of_scale"]) == {"roi_features", "x3_1b", "match_logits"}
+    assert set(p["err_of_scale"]) == {"roi_features", "x3_1b", "match_logits", "bank_rows"}
+    # the bank is extractor output (the shop-side path, once, before the timed region), and its first rows were re-derived by the oracle
+    assert d["bank"]["source"].startswith("extractor output") and d["bank"]["rows_this_rank"] == d["config"]["gallery"]
     assert d["value_clips1"] > 1.0 and d["full_forward_ms_per_clip"] > 0
 
 
