@@ -137,14 +137,18 @@ int seam_conv1x1_sw_f32(const float* x, const float* x2, const float* w, const f
  * stride-1 projection shortcut, FeaturePyramidNetwork.inner_blocks; behind models/video_matchrcnn.py:337] as a STREAMING kernel --
  * weights stationary in LDS, independent waves, 16-byte NHWC pieces in and out -- with the contract of seam_conv2d_f16 /
  * seam_conv2d_dual_f16 (stride2 = 1) on those shapes:
- *   y[M,K] = fp16( act( [x | x2][M, C1 + C2] . w[K, C1 + C2]^T * scale + shift [+ residual[M,K]] ) )
+ *   y[M,K] = fp16( act( [x | x2][M, C1 + C2] . w[K, C1 + C2]^T * scale + shift [+ residual] ) )
+ * res_mode 0: no residual (residual NULL); 1: residual [M,K]; 2 (single source only): residual = coarse NHWC map [N,rH,rW,K] added
+ * through a nearest-neighbour upsample to the [Ho,Wo] output grid (M = N*Ho*Wo, Ho*Wo >= 128; ATen's index rule) -- the FPN top-down
+ * merge [TV FeaturePyramidNetwork.forward] in the conv epilogue, as seam_conv1x1_sw_f32 / seam_conv2d_upres_f32 do in fp32.
  * x, x2, residual, y fp16; w fp16 row-major [K, C1 + C2]; scale / shift fp32 [K] or NULL; fp32 accumulation, fp32 epilogue, one
  * rounding.  Shapes served (seam_conv1x1_swh_config != 0): C1, C2 multiples of 64, C1 + C2 <= 512 (<= 256 for the 256-channel slab
  * K % 256 == 0 takes, <= 128 when K is not a multiple of 128), K a multiple of 64 with K / slab dividing 32; any M > 0.  relu 0 | 1.  Same products as seam_conv2d_f16 in a
  * different accumulation order (agreement to fp32 rounding, not bit for bit); deterministic and independent of M. */
 int seam_conv1x1_swh_config(long long M, int C1, int C2, int K);
 int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const float* scale, const float* shift,
-                         const void* residual, void* y, long long M, int C1, int C2, int K, int relu, seam_stream_t stream);
+                         const void* residual, void* y, long long M, int C1, int C2, int K, int relu, int res_mode,
+                         int Ho, int Wo, int rH, int rW, seam_stream_t stream);
 
 /* Pointwise (1x1, stride 1, pad 0) convolution with a LONG reduction as producer / consumer waves (csrc/seam_pwpc.hip, round 5):
  * the bottleneck reductions of ResNet layer2-4 and the layer4 expansions [TV Bottleneck conv1 / conv3 behind

@@ -49,14 +49,16 @@ struct PwhArgs {
     const _Float16* w;     // [K, C1 + C2] row-major fp16
     const float* scale;    // [K] or null (= 1)
     const float* shift;    // [K] or null (= 0)
-    const _Float16* res;   // [M, K] or null
+    const _Float16* res;   // [M, K] (RES 1) | coarse NHWC map [N, rH, rW, K] added through a nearest-neighbour upsample (RES 2) | null
     _Float16* y;           // [M, K]
     int M, C1, C2, K;
     int relu;
     int ns;                // weight slabs = K / NS
+    int Ho, Wo, rH, rW;    // RES 2: output grid and coarse grid
+    unsigned m_Wo;         // ceil(2^32 / Wo)
 };
 
-template <int MT, int NT, bool DUAL, bool RES>
+template <int MT, int NT, bool DUAL, int RES>
 __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NS = 32 * NT;
@@ -222,13 +224,35 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
         const int ybytes = min(32 * MT, p.M - row0) * p.K * 2;       // rows past M: out of range (loads return 0, stores are dropped)
         const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)row0 * p.K), 0, ybytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((RES ? p.res : p.y) + (size_t)row0 * p.K), 0, ybytes, 0x00020000);
+            (void*)((RES == 1 ? p.res : p.y) + (size_t)row0 * p.K), 0, ybytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(RES == 2 ? p.res : p.y), 0, (int)0x80000000u, 0x00020000);
+        unsigned uo[MT * 2];              // RES == 2: byte offset of the coarse pixel under this lane's row of each half tile
+        if constexpr (RES == 2) {
+            // FPN top-down merge [TV FeaturePyramidNetwork.forward: inner + F.interpolate(top, size, "nearest")]: ATen's index rule
+            // src = min(floor(dst * in / out), in - 1), as seam_conv2d_upres_f32.  img0 = image of the tile's first row (one wave-
+            // uniform division per tile); Ho * Wo >= 32 * MT (host-checked): a row of the tile lies in that image or in the next one
+            const int HoWo = p.Ho * p.Wo;
+            const int img0 = row0 / HoWo;
+            const float fh = (float)p.rH / (float)p.Ho, fw = (float)p.rW / (float)p.Wo;
+#pragma unroll
+            for (int ih = 0; ih < MT * 2; ++ih) {
+                const int rl = min(row0 - img0 * HoWo + 16 * ih + (lane >> 2), p.M - 1 - img0 * HoWo);
+                const int nl = rl >= HoWo ? 1 : 0;
+                const int rm = rl - nl * HoWo;
+                const int ho = (int)__umulhi((unsigned)rm, p.m_Wo);
+                const int wo = rm - ho * p.Wo;
+                const int ht = min((int)floorf((float)ho * fh), p.rH - 1);
+                const int wt = min((int)floorf((float)wo * fw), p.rW - 1);
+                uo[ih] = (unsigned)((((img0 + nl) * p.rH + ht) * p.rW + wt) * p.K + n0 + (lane & 3) * 8) * 2u;
+            }
+        }
         constexpr int STEPS = MT * 2 * NT;
         auto soff_of = [&](int s) { return (16 * (s / NT) * p.K + n0 + 32 * (s % NT)) * 2; };      // wave-uniform byte offset of a step
         constexpr int RESQ = PwhCfg<MT>::RESQ;
         u32x4 rv[RESQ];
         auto request = [&](int s) {
-            if constexpr (RES) rv[s % RESQ] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, e_lane, soff_of(s), 0);
+            if constexpr (RES == 1) rv[s % RESQ] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, e_lane, soff_of(s), 0);
+            if constexpr (RES == 2) rv[s % RESQ] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uo[s / NT], (s % NT) * 64, 0);
         };
         auto steps = [&](auto relu_tag) {
             constexpr bool RELU = decltype(relu_tag)::value;
@@ -244,7 +268,7 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
                 const f32x4 sh0 = *reinterpret_cast<const f32x4*>(v_lane + NS + 32 * j), sh1 = *reinterpret_cast<const f32x4*>(v_lane + NS + 32 * j + 4);
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(tb + t_rd0) * sc0 + sh0;
                 f32x4 v1 = *reinterpret_cast<const f32x4*>(tb + t_rd1) * sc1 + sh1;
-                if constexpr (RES) {
+                if constexpr (RES != 0) {
                     const f16x8 rh = __builtin_bit_cast(f16x8, rv[s % RESQ]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] += (float)rh[e]; v1[e] += (float)rh[e + 4]; }
@@ -297,13 +321,20 @@ extern "C" {
 int seam_conv1x1_swh_config(long long M, int C1, int C2, int K) { return pwh_config(M, C1, C2, K); }
 
 int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const float* scale, const float* shift, const void* residual,
-                         void* y, long long M, int C1, int C2, int K, int relu, void* stream) {
+                         void* y, long long M, int C1, int C2, int K, int relu, int res_mode, int Ho, int Wo, int rH, int rW,
+                         void* stream) {
     const int cfg = pwh_config(M, C1, C2, K);
-    if (!cfg || (C2 > 0 && !x2) || relu < 0 || relu > 1) return (int)hipErrorInvalidValue;
+    if (!cfg || (C2 > 0 && !x2) || relu < 0 || relu > 1 || res_mode < 0 || res_mode > 2 || (res_mode != 0) != (residual != nullptr))
+        return (int)hipErrorInvalidValue;
+    if (res_mode == 2 && (Ho <= 0 || Wo <= 0 || rH <= 0 || rW <= 0 || M % ((long long)Ho * Wo) || (long long)Ho * Wo < 128 ||
+                          (unsigned long long)Ho * Wo * Wo >= (1ull << 32) || (M / ((long long)Ho * Wo)) * rH * rW * K * 2 >= (1ll << 31)))
+        return (int)hipErrorInvalidValue;
     PwhArgs a;
     a.x = (const _Float16*)x; a.x2 = (const _Float16*)x2; a.w = (const _Float16*)w; a.scale = scale; a.shift = shift;
     a.res = (const _Float16*)residual; a.y = (_Float16*)y;
     a.M = (int)M; a.C1 = C1; a.C2 = C2; a.K = K; a.relu = relu;
+    a.Ho = Ho; a.Wo = Wo; a.rH = rH; a.rW = rW;
+    a.m_Wo = res_mode == 2 && Wo > 1 ? (unsigned)(((1ull << 32) + (unsigned)Wo - 1) / (unsigned)Wo) : 0;
     const int MT = cfg / 100, NT = cfg % 100;
     a.ns = K / (32 * NT);
     const int Ct = C1 + C2;
@@ -335,9 +366,12 @@ int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const flo
         else SEAM_PWH_LAUNCH(4, 2, dual, res);                                                                                   \
     } while (0)
     if (C2 > 0) {
-        if (residual) SEAM_PWH_CFG(true, true); else SEAM_PWH_CFG(true, false);
+        if (res_mode == 2) return (int)hipErrorInvalidValue;
+        if (res_mode == 1) SEAM_PWH_CFG(true, 1); else SEAM_PWH_CFG(true, 0);
     } else {
-        if (residual) SEAM_PWH_CFG(false, true); else SEAM_PWH_CFG(false, false);
+        if (res_mode == 2) SEAM_PWH_CFG(false, 2);
+        else if (res_mode == 1) SEAM_PWH_CFG(false, 1);
+        else SEAM_PWH_CFG(false, 0);
     }
 #undef SEAM_PWH_CFG
 #undef SEAM_PWH_LAUNCH

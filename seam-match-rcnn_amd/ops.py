@@ -456,7 +456,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
            and relu in (0, 1, False, True))
     if swh:
         _native.check(lib.seam_conv1x1_swh_f16(_ptr(x), None, _ptr(pc.wsh), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
-                                               n * h * w, c, 0, pc.K, 1 if relu else 0, _stream()), "seam_conv1x1_swh_f16")
+                                               n * h * w, c, 0, pc.K, 1 if relu else 0, 1 if residual is not None else 0, 0, 0, 0, 0,
+                                               _stream()), "seam_conv1x1_swh_f16")
     elif narrow:
         _native.check(lib.seam_linear_narrow_f32(_ptr(x), _ptr(pc.wn), _ptr(pc.shift), _ptr(y), n * h * w, c, pc.K, int(relu), _stream()),
                       "seam_linear_narrow_f32")
@@ -524,6 +525,27 @@ def conv2d_topdown(x: torch.Tensor, pc: PackedConv, top: torch.Tensor) -> torch.
     """FPN top-down merge [TV]: conv(x) + nearest-upsample(top) -> NHWC.  Exact-fp32 weights: ONE launch (the coarse map is
     added in the conv epilogue, ``seam_conv2d_upres_f32``); other precisions: conv + ``upsample_add_``.  Both forms round
     identically."""
+    if (pc.dtype == F16 and pc.wsh is not None and SWH and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4
+            and x.shape[1] * x.shape[2] >= max(SW_MIN_HW, 128) and top.dim() == 4 and top.shape[0] == x.shape[0] and top.shape[3] == pc.K):
+        # fp16 path (round 6): the merge in the streaming pointwise kernel's epilogue -- the lateral is never written and re-read
+        x, top = _req(x, F16, "x"), _req(top, F16, "top")
+        n, h, w, c = x.shape
+        if c != pc.Cstore:
+            raise ValueError(f"conv2d_topdown: input has {c} channels, weights packed for {pc.Cstore}")
+        y = torch.empty((n, h, w, pc.K), dtype=F16, device=x.device)
+        trace = CONV_TRACE
+        if trace is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        lib = _native.lib()
+        _native.check(lib.seam_conv1x1_swh_f16(_ptr(x), None, _ptr(pc.wsh), _ptr(pc.scale), _ptr(pc.shift), _ptr(top), _ptr(y),
+                                               n * h * w, c, 0, pc.K, 0, 2, h, w, top.shape[1], top.shape[2], _stream()),
+                      "seam_conv1x1_swh_f16")
+        if trace is not None:
+            e1.record()
+            trace.append((_swh_variant(lib, n * h * w, c, pc.K), 2.0 * n * h * w * pc.K * (pc.Cin or pc.Cstore), e0, e1,
+                          (n, h, w, c, pc.K, 1, 1), float(2 * (x.numel() + pc.w.numel() + y.numel() + top.numel()))))
+        return y
     if pc.dtype != F32 or pc.K % 4:
         return upsample_add_(conv2d(x, pc), top)
     x = _req(x, None, "x")
@@ -603,7 +625,7 @@ def conv2d_dual(x1: torch.Tensor, x2: torch.Tensor, pc: PackedConv, stride2: int
         _sw_launch(lib, x1, x2, pc, None, y, n * ho * wo, c1, c2, relu)
     elif swh:
         _native.check(lib.seam_conv1x1_swh_f16(_ptr(x1), _ptr(x2), _ptr(pc.wsh), _ptr(pc.scale), _ptr(pc.shift), None, _ptr(y),
-                                               n * ho * wo, c1, c2, pc.K, 1 if relu else 0, _stream()), "seam_conv1x1_swh_f16")
+                                               n * ho * wo, c1, c2, pc.K, 1 if relu else 0, 0, 0, 0, 0, 0, _stream()), "seam_conv1x1_swh_f16")
     else:
         fn = lib.seam_conv2d_dual_f32 if dt == F32 else lib.seam_conv2d_dual_f16
         _native.check(fn(_ptr(x1), _ptr(x2), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, ho, wo, c1,

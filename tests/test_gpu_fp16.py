@@ -402,5 +402,35 @@ def test_pointwise_streaming_kernel_f16_dual_and_unserved(ops):
     dummy = torch.zeros(1 << 16, dtype=H, device=d)
     for (c, kk) in [(96, 256), (1024, 256), (256, 64), (32, 64), (64, 96), (64, 8448 * 2)]:
         assert lib.seam_conv1x1_swh_config(1000, c, 0, kk) == 0
-        assert lib.seam_conv1x1_swh_f16(dummy.data_ptr(), None, dummy.data_ptr(), None, None, None, dummy.data_ptr(), 64, c, 0, kk, 0,
+        assert lib.seam_conv1x1_swh_f16(dummy.data_ptr(), None, dummy.data_ptr(), None, None, None, dummy.data_ptr(), 64, c, 0, kk, 0, 0, 0, 0, 0, 0,
                                         torch.cuda.current_stream().cuda_stream) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 48, 84, 256), (3, 512, 23, 31, 256), (1, 256, 97, 50, 256)])
+def test_fpn_topdown_merge_on_the_streaming_kernel_f16(ops, shape):
+    """conv2d_topdown on the fp16 path (round 6): the lateral 1x1 conv with the coarser level added through a nearest-neighbour
+    upsample in seam_conv1x1_swh_f16's epilogue (res_mode 2) against the fp32 reference of the same fp16-rounded operands
+    [TV FeaturePyramidNetwork.forward: inner + F.interpolate(top, size, "nearest")] and against the two-kernel form it replaces
+    (implicit GEMM + seam_upsample_add_f16: one more fp16 rounding)."""
+    d = dev()
+    n, c, hh, ww, k = shape
+    x = rnd(760, (n, c, hh, ww)).half().float()
+    wt = (rnd(761, (k, c, 1, 1), "w") / math.sqrt(c)).half().float()
+    bias = rnd(762, (k,), "b") * 0.1
+    top = rnd(763, (n, k, (hh + 1) // 2, (ww + 1) // 2)).half().float()
+    ref = F.conv2d(x, wt, bias) + F.interpolate(top, size=(hh, ww), mode="nearest")
+    pc = ops.pack_conv(wt.to(d), bias.to(d), dtype=H)
+    xd, td = nhwc(x).half().to(d), nhwc(top).half().to(d)
+    saved, ops.CONV_TRACE = ops.SWH, []
+    try:
+        ops.SWH = True
+        got = ops.conv2d_topdown(xd, pc, td)
+        assert ops.CONV_TRACE[0][0].startswith("conv1x1_swh"), ops.CONV_TRACE[0][0]
+        ops.CONV_TRACE = None
+        assert torch.equal(ops.conv2d_topdown(xd, pc, td), got)
+        ops.SWH = False
+        two = ops.conv2d_topdown(xd, pc, td)
+    finally:
+        ops.SWH, ops.CONV_TRACE = saved, None
+    assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
+    assert float((got.float() - two.float()).abs().max()) <= 2.0 ** -8 * float(two.float().abs().max())

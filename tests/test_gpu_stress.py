@@ -440,23 +440,34 @@ def stress_swh(rng):
         done += 1
         g = gen(rng)
         relu = rng.choice([0, 1])
-        use_res = rng.random() < 0.4
-        desc = f"M={m} c={c1}+{c2} k={k} relu={relu} res={int(use_res)} cfg={lib.seam_conv1x1_swh_config(m, c1, c2, k)}"
+        res_mode = rng.choice([0, 0, 1, 2]) if not dual else rng.choice([0, 0, 1])
+        if res_mode == 2 and h * w < 128:
+            res_mode = 1
+        desc = f"n={n} {h}x{w} c={c1}+{c2} k={k} relu={relu} res_mode={res_mode} cfg={lib.seam_conv1x1_swh_config(m, c1, c2, k)}"
         say("START conv1x1_swh", desc)
         x = torch.randn(m, c, device=dev, generator=g).half()
         wt = (torch.randn(k, c, device=dev, generator=g) / math.sqrt(c)).half()
         scale, shift = epilogue_vectors(rng, k, g)
-        res = torch.randn(m, k, device=dev, generator=g).half() if use_res else None
+        rh, rw = (h + 1) // 2, (w + 1) // 2
+        res = full = None
+        if res_mode == 1:
+            res = full = torch.randn(m, k, device=dev, generator=g).half()
+        elif res_mode == 2:         # FPN top-down merge: a coarse map under a nearest-neighbour upsample
+            res = torch.randn(n, rh, rw, k, device=dev, generator=g).half()
+            full = F.interpolate(res.permute(0, 3, 1, 2).float(), size=(h, w), mode="nearest").permute(0, 2, 3, 1).reshape(m, k).half()
         xa = x[:, :c1].contiguous() if dual else x
         xb = x[:, c1:].contiguous() if dual else None
         outs = []
         for rep in range(2):
             y = poisoned((m, k), torch.float16, rep)
-            rc = lib.seam_conv1x1_swh_f16(P(xa), P(xb), P(wt), P(scale), P(shift), P(res), P(y), m, c1, c2, k, relu, st())
+            rc = lib.seam_conv1x1_swh_f16(P(xa), P(xb), P(wt), P(scale), P(shift), P(res), P(y), m, c1, c2, k, relu, res_mode,
+                                          h if res_mode == 2 else 0, w if res_mode == 2 else 0, rh if res_mode == 2 else 0,
+                                          rw if res_mode == 2 else 0, st())
             assert rc == 0, (desc, rc)
             outs.append(y)
         acc = x.float() @ wt.float().t()
-        refs = [("torch fp32 matmul", torch_epilogue(acc, scale, shift, None if res is None else res.float(), relu))]
+        refs = [("torch fp32 matmul", torch_epilogue(acc, scale, shift, None if full is None else full.float(), relu))]
+        res = full.contiguous() if full is not None else None
         wi = torch.empty((lib.seam_conv_rows_padded(k), lib.seam_conv_kred_f16(c, 1, 1)), dtype=torch.float16, device=dev)
         wf = wt.float()
         assert lib.seam_pack_conv_weight_f16(P(wf), P(wi), k, c, 1, 1, c, 0, st()) == 0
@@ -466,7 +477,7 @@ def stress_swh(rng):
         check("conv1x1_swh", desc, outs[0], outs[1], refs, 2e-3)
     dummy = torch.zeros(1 << 16, dtype=torch.float16, device=dev)
     for (c, k) in [(96, 256), (1024, 256), (32, 64), (64, 96), (576, 128), (256, 64)]:
-        if lib.seam_conv1x1_swh_f16(P(dummy), None, P(dummy), None, None, None, P(dummy), 64, c, 0, k, 0, st()) == 0:
+        if lib.seam_conv1x1_swh_f16(P(dummy), None, P(dummy), None, None, None, P(dummy), 64, c, 0, k, 0, 0, 0, 0, 0, 0, st()) == 0:
             fails.append(("conv1x1_swh", f"c={c} k={k}", "unserved channel count was not refused"))
     say(f"SUMMARY conv1x1_swh cases {done} seconds {time.time() - t0:.1f}")
 
