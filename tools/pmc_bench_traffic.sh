@@ -36,6 +36,11 @@ for i in range($i):
             a = agg[r["Counter_Name"]]["conv3x3_f16pc"]
             a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             continue
+        mh = re.search(r"pw_swh_kernel<(\d+), *(\d+)", r["Kernel_Name"])
+        if mh:
+            a = agg[r["Counter_Name"]][f"conv1x1_swh<{mh.group(1)},{mh.group(2)}>"]
+            a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            continue
         ms = re.search(r"pw_sw_kernel<(\d+), *(\d+)", r["Kernel_Name"])
         if ms:
             a = agg[r["Counter_Name"]][f"conv1x1_sw<{ms.group(1)},{ms.group(2)}>"]
