@@ -150,6 +150,15 @@ int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const flo
                          const void* residual, void* y, long long M, int C1, int C2, int K, int relu, int res_mode,
                          int Ho, int Wo, int rH, int rW, seam_stream_t stream);
 
+/* The ResNet stem [TV ResNet.conv1 7x7 / stride 2 / pad 3 + bn1 + relu; behind models/video_matchrcnn.py:337] of the fp16 path on the
+ * PADDED space-to-depth frame, as the streaming kernel above (csrc/seam_pwh.hip, round 6): xpad fp16 [N, Ho + 3, Wo + 3, 16] = the
+ * frame of seam_preprocess_s2d_batch_f16 with 2 zero cells before and 1 after in both directions; w fp16 [64, 256] row-major with
+ * k = (4 r + s) * 16 + channel (the re-indexed weights of seam_conv2d_crop_f16's call site); scale / shift fp32 [64] or NULL;
+ * y fp16 [N, Ho, Wo, 64].  A tap is a constant shift of the flattened padded index, so every A fragment is one contiguous 1 KB run.
+ * Same products as seam_conv2d_crop_f16, fp32 accumulation in tap-major order (agreement to fp32 rounding); deterministic. */
+int seam_stem_s2d_swh_f16(const void* xpad, const void* w, const float* scale, const float* shift, void* y, int N, int Ho, int Wo,
+                          int relu, seam_stream_t stream);
+
 /* Pointwise (1x1, stride 1, pad 0) convolution with a LONG reduction as producer / consumer waves (csrc/seam_pwpc.hip, round 5):
  * the bottleneck reductions of ResNet layer2-4 and the layer4 expansions [TV Bottleneck conv1 / conv3 behind
  * models/video_matchrcnn.py:337], exact fp32 on v_mfma_f32_32x32x2_f32, the same contract as seam_conv2d_f32 on those shapes:
@@ -208,6 +217,10 @@ int seam_preprocess_s2d_batch_f32(const float* imgs, size_t img_stride, float* o
 /* fp16 output: [n, Hp/2, Wp/2, 16] -- the 12 channels above + 4 zeros (the fp16 GEMM reads 8-channel vectors). */
 int seam_preprocess_s2d_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w,
                                   int out_h, int out_w, int Hp, int Wp, seam_stream_t stream);
+/* The same frame with pad_lo zero cells before and pad_hi after it in both directions: out [n, Hp/2 + pad_lo + pad_hi,
+ * Wp/2 + pad_lo + pad_hi, 16] -- the input layout of seam_stem_s2d_swh_f16 (pad_lo 2, pad_hi 1: the 4x4 / pad-2 form of the stem). */
+int seam_preprocess_s2d_pad_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w, int out_h,
+                                      int out_w, int Hp, int Wp, int pad_lo, int pad_hi, seam_stream_t stream);
 
 /* Same transform fed by a uint8 HWC RGB frame [in_h,in_w,3]: fuses ToTensor (x/255, stuffs/transform.py:46-49)
  * so a clip crosses PCIe at 1 byte per sample (device side).  out: fp32 NHWC4 or, when

@@ -49,6 +49,7 @@ SIGNATURES = {
     "seam_conv2d_crop_f16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_s2d_batch_f32": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_preprocess_s2d_batch_f16": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_preprocess_s2d_pad_batch_f16": (_i, [_p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv1x1_pc_supported": (_i, [C.c_longlong, _i, _i]),
     "seam_conv1x1_pc_weight_floats": (C.c_longlong, [_i, _i]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "seam_conv1x1_sw_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv1x1_swh_config": (_i, [C.c_longlong, _i, _i, _i]),
     "seam_conv1x1_swh_f16": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "seam_stem_s2d_swh_f16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_upres_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_pack_conv_weight_bx3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -72,11 +72,16 @@ __global__ void preprocess_kernel(const float* __restrict__ img, T* __restrict__
 // padded 4th colour channel: the NHWC4 form spends 224 steps on 147 products) whose gathers are 48-byte pixels.
 template <typename T>
 __global__ void preprocess_s2d_kernel(const float* __restrict__ img, T* __restrict__ out, int in_h, int in_w,
-                                      int out_h, int out_w, int Hp, int Wp, size_t img_stride) {
-    const int X = blockIdx.x * blockDim.x + threadIdx.x;
-    const int Y = blockIdx.y;
+                                      int out_h, int out_w, int Hp, int Wp, size_t img_stride, int pad_lo, int pad_hi) {
+    // pad_lo / pad_hi (round 6): zero cells written before / after the frame in both directions -- the grid covers the padded frame
+    // [H2 + pad_lo + pad_hi, W2 + pad_lo + pad_hi]; cells outside the frame proper fall through the (y, x) range test below as zeros
+    const int Xo = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Yo = blockIdx.y;
     const int W2 = Wp >> 1, H2 = Hp >> 1;
-    if (X >= W2) return;
+    const int W2p = W2 + pad_lo + pad_hi, H2p = H2 + pad_lo + pad_hi;
+    if (Xo >= W2p) return;
+    const int X = Xo - pad_lo, Y = Yo - pad_lo;
+    const bool inside = X >= 0 && X < W2 && Y >= 0 && Y < H2;
     img += (size_t)blockIdx.z * img_stride;
     float o[12];
     const float mean[3] = {0.485f, 0.456f, 0.406f};
@@ -85,7 +90,7 @@ __global__ void preprocess_s2d_kernel(const float* __restrict__ img, T* __restri
     for (int d = 0; d < 4; ++d) {
         const int y = 2 * Y + (d >> 1), x = 2 * X + (d & 1);
         float v[3] = {0.f, 0.f, 0.f};
-        if (y < out_h && x < out_w) {
+        if (inside && y < out_h && x < out_w) {
             if (out_h == in_h && out_w == in_w) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) v[c] = (img[((size_t)c * in_h + y) * in_w + x] - mean[c]) / stdv[c];
@@ -111,14 +116,14 @@ __global__ void preprocess_s2d_kernel(const float* __restrict__ img, T* __restri
     }
     if constexpr (sizeof(T) == 2) {             // fp16: 16 channels per cell (12 + 4 zeros: the fp16 GEMM reads 8-channel vectors), 32 bytes
         typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-        T* dst = out + (((size_t)blockIdx.z * H2 + Y) * W2 + X) * 16;
+        T* dst = out + (((size_t)blockIdx.z * H2p + Yo) * W2p + Xo) * 16;
         h16x8 a, b;
 #pragma unroll
         for (int c = 0; c < 8; ++c) { a[c] = (_Float16)o[c]; b[c] = (_Float16)(c < 4 ? o[8 + c] : 0.f); }
         *reinterpret_cast<h16x8*>(dst) = a;
         *reinterpret_cast<h16x8*>(dst + 8) = b;
     } else {
-        T* dst = out + (((size_t)blockIdx.z * H2 + Y) * W2 + X) * 12;
+        T* dst = out + (((size_t)blockIdx.z * H2p + Yo) * W2p + Xo) * 12;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             f32x4 v4 = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
@@ -333,17 +338,22 @@ int seam_preprocess_s2d_batch_f32(const float* imgs, size_t img_stride, float* o
     if (n < 1 || n > 65535 || (Hp & 1) || (Wp & 1)) return (int)hipErrorInvalidValue;
     dim3 grid((Wp / 2 + 127) / 128, Hp / 2, n);
     hipLaunchKernelGGL(preprocess_s2d_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, imgs, out, in_h, in_w, out_h, out_w,
-                       Hp, Wp, img_stride);
+                       Hp, Wp, img_stride, 0, 0);
+    return (int)hipGetLastError();
+}
+
+int seam_preprocess_s2d_pad_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w, int out_h, int out_w,
+                                      int Hp, int Wp, int pad_lo, int pad_hi, void* stream) {
+    if (n < 1 || n > 65535 || (Hp & 1) || (Wp & 1) || pad_lo < 0 || pad_hi < 0 || pad_lo > 8 || pad_hi > 8) return (int)hipErrorInvalidValue;
+    dim3 grid((Wp / 2 + pad_lo + pad_hi + 127) / 128, Hp / 2 + pad_lo + pad_hi, n);
+    hipLaunchKernelGGL(preprocess_s2d_kernel<_Float16>, grid, dim3(128), 0, (hipStream_t)stream, imgs, (_Float16*)out, in_h, in_w,
+                       out_h, out_w, Hp, Wp, img_stride, pad_lo, pad_hi);
     return (int)hipGetLastError();
 }
 
 int seam_preprocess_s2d_batch_f16(const float* imgs, size_t img_stride, void* out, int n, int in_h, int in_w, int out_h, int out_w,
                                   int Hp, int Wp, void* stream) {
-    if (n < 1 || n > 65535 || (Hp & 1) || (Wp & 1)) return (int)hipErrorInvalidValue;
-    dim3 grid((Wp / 2 + 127) / 128, Hp / 2, n);
-    hipLaunchKernelGGL(preprocess_s2d_kernel<_Float16>, grid, dim3(128), 0, (hipStream_t)stream, imgs, (_Float16*)out, in_h, in_w,
-                       out_h, out_w, Hp, Wp, img_stride);
-    return (int)hipGetLastError();
+    return seam_preprocess_s2d_pad_batch_f16(imgs, img_stride, out, n, in_h, in_w, out_h, out_w, Hp, Wp, 0, 0, stream);
 }
 
 int seam_preprocess_u8(const uint8_t* img, void* out, int in_h, int in_w, int out_h, int out_w, int Hp, int Wp, int out_f16,

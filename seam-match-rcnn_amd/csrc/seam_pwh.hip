@@ -117,8 +117,7 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
     // A stream: (tile, k-step) pairs in order; loads run 4 k-steps ahead of the MFMAs, across tile boundaries.  The descriptor
     // of the tile being fetched covers exactly its rows (rows past M and tiles past the end of this wave's list have no records:
     // the loads stay unconditional and return zeros nobody uses)
-    // ring depth RD k-steps
-    constexpr int RD = 4;        // (8 for the one-row-tile form was tried: hipcc then spills ~56 registers per lane in every <1,8> instance)
+    constexpr int RD = 4;        // ring depth in k-steps (8 for the one-row-tile form was tried: hipcc spills ~56 registers per lane)
     f16x8 ring[RD][MT];
     int ld_tt = tt, ld_ks = 0;                   // position of the NEXT load of the stream
     // (gfx950 range-checks vector offset + scalar offset + immediate against the descriptor's size -- tools/probes/soffset_probe.hip,
@@ -156,12 +155,11 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
     int bj0 = b_lane;                            // B fragment pointer of n-tile 0: slab row (l & 31), k-slot (l >> 5), current trip; n-tile j
     const int bstep = 32 * LDW;                  // sits bstep * j further (one v_add per read: nothing here is bound by the vector ALU)
 
-    // four k-steps (half / one trip around the A ring; `half` = ring slots 4 half .. 4 half + 3).  FIRST: the tile's first trip
-    // multiplies into the constant 0.  LAST: the tile's last trip does not fetch B fragments past its end -- the next tile reads its
-    // first ones itself, so that none are carried (32 registers) across the epilogue, where the residual ring needs them.
-    auto trip = [&](int ks0, auto half_tag, auto first_tag) {
+    // four k-steps (one trip around the A ring).  FIRST: the tile's first trip multiplies into the constant 0.  LAST: the tile's last
+    // trip does not fetch B fragments past its end -- the next tile reads its first ones itself, so that none are carried (32
+    // registers) across the epilogue, where the residual ring needs them.
+    auto trip = [&](int ks0, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr int half = decltype(half_tag)::value;
         const bool last = ks0 + 4 >= nks;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -173,7 +171,7 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
             for (int j = 0; j < NT; ++j) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const f16x8 av = ring[(4 * half + u) % RD][i];
+                    const f16x8 av = ring[u][i];
                     if (FIRST && u == 0) {
                         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, fb[j], z, 0, 0, 0);
@@ -184,38 +182,16 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
                 if (!(last && u == 3)) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj0 + j * bstep + (u < 3 ? (u + 1) * 32 : 0)));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            issue_a(ring[(4 * half + u) % RD]);
+            issue_a(ring[u]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    int ph = 0;
     for (; tt < tiles_x; tt += wstride) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj0 + j * bstep));
-        using H0 = std::integral_constant<int, 0>;
-        using H1 = std::integral_constant<int, 1>;
-        if constexpr (RD == 8) {
-            // the ring's phase: a tile of nks k-steps advances it by nks mod 8 (0 or 4) slots -- `ph` = the half its first trip reads
-            // (wave-uniform; the half is a compile-time constant of each trip: register sets are never selected at run time)
-            if (ph == 0) {
-                trip(0, H0{}, std::true_type{});
-                for (int ks0 = 4; ks0 < nks; ks0 += 8) {
-                    trip(ks0, H1{}, std::false_type{});
-                    if (ks0 + 4 < nks) trip(ks0 + 4, H0{}, std::false_type{});
-                }
-            } else {
-                trip(0, H1{}, std::true_type{});
-                for (int ks0 = 4; ks0 < nks; ks0 += 8) {
-                    trip(ks0, H0{}, std::false_type{});
-                    if (ks0 + 4 < nks) trip(ks0 + 4, H1{}, std::false_type{});
-                }
-            }
-            ph = (ph + (nks >> 2)) & 1;
-        } else {
-            trip(0, H0{}, std::true_type{});
-            for (int ks0 = 4; ks0 < nks; ks0 += 4) trip(ks0, H0{}, std::false_type{});
-        }
+        trip(0, std::true_type{});
+        for (int ks0 = 4; ks0 < nks; ks0 += 4) trip(ks0, std::false_type{});
 
         // ---- epilogue: y = act(acc * scale + shift [+ residual]) -> fp16, through the wave-private transpose --------------
         // Steps s = (i, h, j) = half an MFMA tile each: 16 pixel rows x 32 channels; a lane finishes row (l >> 2), 8 channels at
@@ -286,6 +262,166 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void pw_swh_kernel(const PwhArgs
                 //  scalar offset -- and the store then writes the NEXT step's values: seen here as NaNs in the <2,4> residual form, in
                 //  seam_pwpc.hip as wrong fourth channels.  tools/isa_store_hazard.py scans the library's ISA for the pattern.)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, e_lane + (unsigned)soff_of(s), 0, 0);
+            }
+        };
+        if (p.relu) steps(std::true_type{});
+        else steps(std::false_type{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The ResNet stem on the space-to-depth frame as the same streaming kernel (round 6).
+// ResNet.conv1 (7x7 / stride 2 / pad 3) on the frame seam_preprocess_s2d_batch_f16 writes is a 4 x 4 / stride-1 convolution over
+// 16-channel cells (seam_conv2d_crop_f16): 16 taps x 16 channels = 16 k-steps of v_mfma_f32_32x32x16_f16, 64 output channels.  On a
+// frame PADDED with zero cells (2 before, 1 after, in both directions; pitch Wp cells) the tap (r, s) of output position m (flattened
+// over the padded grid, m = (n Hp + y) Wp + x) is the cell m + r Wp + s: a tap is a constant shift of the flattened index, so a
+// wave tile = 32 MT CONSECUTIVE positions reads, per tap, one contiguous run of 32 MT cells (1 KB per load instruction, 16 bytes per
+// lane) -- the implicit GEMM gathered the sixteen 32-byte cells of every output pixel one by one and ran at 0.23 of the HBM roof.
+// Positions in the padding columns / rows (1.2 % of the grid) are computed and not stored; the output is the dense NHWC map.
+struct StemArgs {
+    const _Float16* x;     // padded frame [N, Hp, Wp, 16]
+    const _Float16* w;     // [64, 256] row-major fp16, k = (4 r + s) * 16 + channel
+    const float* scale;    // [64] or null
+    const float* shift;    // [64] or null
+    _Float16* y;           // [N, Ho, Wo, 64]
+    int N, Hp, Wp, Ho, Wo, relu;
+    long long Mp;          // N * Hp * Wp
+    unsigned m_HpWp, m_Wp; // ceil(2^32 / d)
+};
+
+__global__ __launch_bounds__(64 * PWH_WAVES, 1) void stem_swh_kernel(const StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 4, NT = 2, NS = 64, Ct = 256, LDW = Ct * 2 + 16, RD = 4, nks = 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const vec = reinterpret_cast<float*>(smem + NS * LDW + PWH_WAVES * TBUF);       // [2][NS]: scale, shift
+    for (int v = tid; v < NS * (Ct >> 3); v += 64 * PWH_WAVES) {
+        const int r = v / (Ct >> 3), c8 = v - r * (Ct >> 3);
+        *reinterpret_cast<f32x4*>(smem + r * LDW + c8 * 16) = *reinterpret_cast<const f32x4*>(p.w + (size_t)r * Ct + c8 * 8);
+    }
+    for (int v = tid; v < NS; v += 64 * PWH_WAVES) {
+        vec[v] = p.scale ? p.scale[v] : 1.f;
+        vec[NS + v] = p.shift ? p.shift[v] : 0.f;
+    }
+    __syncthreads();
+    char* const tb = smem + NS * LDW + wid * TBUF;
+
+    // tiles of 128 consecutive flattened positions, dealt to the block's waves in block-contiguous order
+    const long long tiles = (p.Mp + 32 * MT - 1) / (32 * MT);
+    const long long wstride = (long long)gridDim.x * PWH_WAVES;
+    long long tt = (long long)blockIdx.x * PWH_WAVES + wid;
+    if (tt >= tiles) return;
+
+    const unsigned a_lane = (unsigned)((lane & 31) * 32 + (lane >> 5) * 16);
+    const int b_lane = (int)(unsigned)(size_t)(lds_char*)smem + (lane & 31) * LDW + (lane >> 5) * 16;
+    const int t_wr0 = ((lane >> 5) * 4) * 128 + ((lane & 31) >> 2) * 16 + (lane & 3) * 4;
+    const int t_wr1 = ((lane >> 5) * 4) * 128 + ((((lane & 31) >> 2)) ^ 1) * 16 + (lane & 3) * 4;
+    const int t_par = (lane >> 2) & 1;
+    const int t_rd0 = (lane >> 2) * 128 + (((lane & 3) * 2) ^ t_par) * 16;
+    const int t_rd1 = (lane >> 2) * 128 + (((lane & 3) * 2 + 1) ^ t_par) * 16;
+    const float* const v_lane = vec + (lane & 3) * 8;
+
+    f16x8 ring[RD][MT];
+    long long ld_tt = tt;
+    int ld_ks = 0;
+    __amdgpu_buffer_rsrc_t ld_rs;
+    auto set_ld_tile = [&](long long t) {            // everything from the tile's first position to the end of the frame (<= 2^31 - 1 bytes)
+        const long long row0 = t * (32 * MT);
+        const long long left = t < tiles ? (p.Mp - row0) * 32 : 0;
+        ld_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)(t < tiles ? row0 : 0) * 16), 0,
+                                                  (int)(left > 0x7fffffffLL ? 0x7fffffffLL : left), 0x00020000);
+    };
+    set_ld_tile(tt);
+    auto issue_a = [&](f16x8 (&slot)[MT]) {          // k-step ld_ks = tap (r, s) = (ld_ks >> 2, ld_ks & 3): the cells r Wp + s further on
+        const int so = ((ld_ks >> 2) * p.Wp + (ld_ks & 3)) * 32;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            slot[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(ld_rs, a_lane, so + i * 32 * 32, 0));
+        if (++ld_ks == nks) { ld_ks = 0; ld_tt += wstride; set_ld_tile(ld_tt); }
+    };
+#pragma unroll
+    for (int s = 0; s < RD; ++s) issue_a(ring[s]);
+
+    f32x16 acc[MT][NT];
+    f16x8 fb[NT];
+    int bj0 = b_lane;
+    constexpr int bstep = 32 * LDW;
+    auto trip = [&](int ks0, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const bool last = ks0 + 4 >= nks;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u == 3) bj0 += !last ? 128 : -(nks - 4) * 32;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (FIRST && u == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[u][i], fb[j], z, 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[u][i], fb[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+                if (!(last && u == 3)) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj0 + j * bstep + (u < 3 ? (u + 1) * 32 : 0)));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            issue_a(ring[u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int HpWp = p.Hp * p.Wp;
+    for (; tt < tiles; tt += wstride) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj0 + j * bstep));
+        trip(0, std::true_type{});
+        for (int ks0 = 4; ks0 < nks; ks0 += 4) trip(ks0, std::false_type{});
+
+        // ---- epilogue: the dense position of every row of the tile (or none: padding columns / rows), then as conv1x1_swh ----
+        const long long row0 = tt * (32 * MT);
+        const int n0 = (int)(row0 / HpWp);                                  // image of the tile's first position (wave-uniform)
+        const int rem0 = (int)(row0 - (long long)n0 * HpWp);
+        const int y0 = rem0 / p.Wp;
+        // dense base of the tile: the first pixel of output row min(y0, Ho - 1) of image n0; every valid position of the tile lies at
+        // or behind it (a tile is 128 positions: at most into the next image), within a few rows -- 32-bit lane offsets from there
+        const long long base_d = ((long long)n0 * p.Ho + min(y0, p.Ho - 1)) * p.Wo;
+        const long long left_d = ((long long)p.N * p.Ho * p.Wo - base_d) * 128;
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.y + (size_t)base_d * 64), 0, (int)(left_d > 0x7fffffffLL ? 0x7fffffffLL : left_d), 0x00020000);
+        unsigned uo[MT * 2];
+#pragma unroll
+        for (int ih = 0; ih < MT * 2; ++ih) {
+            const int rl = rem0 + 16 * ih + (lane >> 2);                    // position relative to image n0's padded grid (may run into n0 + 1)
+            const int nl = rl >= HpWp ? 1 : 0;
+            const int rm = rl - nl * HpWp;
+            const int yy = (int)__umulhi((unsigned)rm, p.m_Wp);
+            const int xx = rm - yy * p.Wp;
+            const bool ok = yy < p.Ho && xx < p.Wo && n0 + nl < p.N;
+            const long long d = ((long long)(n0 + nl) * p.Ho + yy) * p.Wo + xx - base_d;
+            uo[ih] = ok ? (unsigned)(d * 128) + (unsigned)((lane & 3) * 16) : 0x80000000u;
+        }
+        constexpr int STEPS = MT * 2 * NT;
+        auto steps = [&](auto relu_tag) {
+            constexpr bool RELU = decltype(relu_tag)::value;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const int ih = s / NT, i = ih >> 1, h = ih & 1, j = s % NT;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    *reinterpret_cast<float*>(tb + ((r & 1) ? t_wr1 : t_wr0) + ((r & 3) + 8 * (r >> 2)) * 128) = acc[i][j][8 * h + r];
+                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(v_lane + 32 * j), sc1 = *reinterpret_cast<const f32x4*>(v_lane + 32 * j + 4);
+                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(v_lane + NS + 32 * j), sh1 = *reinterpret_cast<const f32x4*>(v_lane + NS + 32 * j + 4);
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(tb + t_rd0) * sc0 + sh0;
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(tb + t_rd1) * sc1 + sh1;
+                if constexpr (RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                }
+                f16x8 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hv[e] = (_Float16)v0[e]; hv[e + 4] = (_Float16)v1[e]; }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, uo[ih] + (unsigned)(j * 64), 0, 0);
             }
         };
         if (p.relu) steps(std::true_type{});
@@ -376,6 +512,36 @@ int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const flo
 #undef SEAM_PWH_CFG
 #undef SEAM_PWH_LAUNCH
     if (e != hipSuccess) return (int)e;
+    return (int)hipGetLastError();
+}
+
+// ResNet.conv1 + bn1 + relu [TV; behind models/video_matchrcnn.py:337] on the PADDED space-to-depth frame (fp16): xpad [N, Ho + 3,
+// Wo + 3, 16] = the frame of seam_preprocess_s2d_batch_f16 with 2 zero cells before and 1 after in both directions; w fp16 [64, 256],
+// k = (4 r + s) * 16 + channel (the re-indexed 7x7 weights of seam_conv2d_crop_f16's call site); y fp16 [N, Ho, Wo, 64] dense.
+// Same products as seam_conv2d_crop_f16 on the unpadded frame, fp32 accumulation in tap-major order; deterministic.
+int seam_stem_s2d_swh_f16(const void* xpad, const void* w, const float* scale, const float* shift, void* y, int N, int Ho, int Wo,
+                          int relu, void* stream) {
+    if (N <= 0 || Ho <= 0 || Wo <= 0 || relu < 0 || relu > 1) return (int)hipErrorInvalidValue;
+    StemArgs a;
+    a.x = (const _Float16*)xpad; a.w = (const _Float16*)w; a.scale = scale; a.shift = shift; a.y = (_Float16*)y;
+    a.N = N; a.Ho = Ho; a.Wo = Wo; a.Hp = Ho + 3; a.Wp = Wo + 3; a.relu = relu;
+    a.Mp = (long long)N * a.Hp * a.Wp;
+    if ((long long)a.Hp * a.Wp >= (1ll << 31) / 2 || (unsigned long long)a.Hp * a.Wp * a.Wp >= (1ull << 32)) return (int)hipErrorInvalidValue;
+    a.m_HpWp = 0;
+    a.m_Wp = (unsigned)(((1ull << 32) + (unsigned)a.Wp - 1) / (unsigned)a.Wp);
+    const size_t lds = (size_t)64 * (256 * 2 + 16) + PWH_WAVES * TBUF + 2 * 64 * 4;
+    const long long tiles = (a.Mp + 127) / 128;
+    long long nblk = (tiles + PWH_WAVES - 1) / PWH_WAVES;
+    if (nblk > 256) nblk = 256;
+    static std::atomic<unsigned> attr_done{0};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!(attr_done.load(std::memory_order_acquire) & (1u << (dev_ & 31)))) {
+        const hipError_t e = hipFuncSetAttribute((const void*)stem_swh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e != hipSuccess) return (int)e;
+        attr_done.fetch_or(1u << (dev_ & 31), std::memory_order_release);
+    }
+    hipLaunchKernelGGL(stem_swh_kernel, dim3((unsigned)nblk), dim3(64 * PWH_WAVES), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

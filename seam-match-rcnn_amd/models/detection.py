@@ -82,7 +82,10 @@ class GeneralizedRCNNTransform(nn.Module):
         wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
         # fp32 / fp16 paths with float images: space-to-depth layout for the 4x4 / stride-1 form of the stem (STEM_S2D)
         s2d = STEM_S2D and cdt(self) in (torch.float32, torch.float16) and all(i.dtype == torch.float32 for i in images)
-        return ops.preprocess(images, sizes, hp, wp, adt(self), s2d=s2d), sizes, orig, (hp, wp)
+        # fp16 path: the frame comes with the zero cells the streaming stem kernel wants around it (2 before, 1 after); the body
+        # recognises that form by its shape (hp, wp are multiples of 32, so a padded side is 3 mod 16, a plain one 0)
+        pad = (2, 1) if (s2d and STEM_SWH and adt(self) == torch.float16 and d % 32 == 0) else (0, 0)
+        return ops.preprocess(images, sizes, hp, wp, adt(self), s2d=s2d, s2d_pad=pad), sizes, orig, (hp, wp)
 
     @staticmethod
     def rescale_boxes(boxes: torch.Tensor, from_hw, to_hw) -> torch.Tensor:
@@ -118,6 +121,9 @@ FUSE_SHORTCUT = _os.environ.get("SEAM_FUSE_SHORTCUT", "1") != "0"
 # The stem on a space-to-depth input: 7x7 / stride 2 / pad 3 over 3 colours == 4x4 / stride 1 / pad (2 before, 1 after) over the 12
 # channels (dy, dx, c) -- the same 147 products per output in 192 reduction steps instead of 224 (SEAM_STEM_S2D=0: NHWC4 form).
 STEM_S2D = _os.environ.get("SEAM_STEM_S2D", "1") != "0"
+# fp16 path: the stem on the streaming kernel over the zero-padded space-to-depth frame (csrc/seam_pwh.hip stem_swh_kernel, round 6);
+# SEAM_STEM_SWH=0 keeps the implicit GEMM (seam_conv2d_crop_f16)
+STEM_SWH = _os.environ.get("SEAM_STEM_SWH", "1") != "0"
 # ResNet body: batch slices on this many HIP streams (bit-identical results, tested).  2 since round 2: the tail of one slice's launch
 # (3.05 rounds of tiles cost 4) runs under the other slice's next layer: 119.8 vs 121.5 ms per 8-clip step, 16.6 vs 17.0 ms at one
 # clip per step, one box (profiles/r02_body_streams.txt); 3 streams give less, 1 restores the single-stream walk.
@@ -170,6 +176,9 @@ class ResNet50Body(nn.Module):
                     ws = w8.view(64, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(64, 12, 4, 4).contiguous()
                     pk["stem_s2d"] = ops.pack_conv(ws, None, self.bn1.tensors(), stride=1, pad=2, cstore=12 if dt == torch.float32 else 16,
                                                    bn_eps=self.bn1.eps, wino=False, dtype=dt)
+                    if dt == torch.float16 and STEM_SWH:
+                        # the streaming form of the fp16 stem (ops.stem_s2d_f16): rows [64, (r, s, 16 channels)] of the same weights
+                        pk["stem_rows"] = F.pad(ws, (0, 0, 0, 0, 0, 4)).permute(0, 2, 3, 1).reshape(64, 256).to(torch.float16).contiguous()
                 for li in range(1, 5):
                     for bi, b in enumerate(getattr(self, f"layer{li}")):
                         e = {"c1": ops.pack_conv(b.conv1.weight, None, b.bn1.tensors(), bn_eps=b.bn1.eps, dtype=dt),
@@ -198,7 +207,8 @@ class ResNet50Body(nn.Module):
             if (getattr(self, "_streams", None) is None or len(self._streams) != BODY_STREAMS
                     or self._streams[0].device != x.device):            # rebuilt after model.to(another device)
                 self._streams = [torch.cuda.Stream(device=x.device) for _ in range(BODY_STREAMS)]
-            h1, w1 = ((x.shape[1], x.shape[2]) if x.shape[-1] in (12, 16) else
+            spad = 3 if (x.shape[-1] == 16 and x.shape[1] % 16 == 3 and x.shape[2] % 16 == 3) else 0      # padded s2d frame (fp16 path)
+            h1, w1 = ((x.shape[1] - spad, x.shape[2] - spad) if x.shape[-1] in (12, 16) else
                       ((x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1))
             hh, ww = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
             outs = []
@@ -219,7 +229,13 @@ class ResNet50Body(nn.Module):
 
     def _run(self, x, pk, outs):
         if x.shape[-1] in (12, 16):    # space-to-depth input [N,H/2,W/2,12] (fp16: 16): the stem as a 4x4 / stride-1 conv, output grid = input grid
-            x = ops.conv2d(x, pk["stem_s2d"], relu=True, out_hw=(x.shape[1], x.shape[2]))
+            pre_padded = x.shape[-1] == 16 and x.shape[1] % 16 == 3 and x.shape[2] % 16 == 3
+            if "stem_rows" in pk and x.dtype == torch.float16 and x.shape[-1] == 16:
+                x = ops.stem_s2d_f16(x, pk["stem_rows"], pk["stem_s2d"].scale, pk["stem_s2d"].shift, relu=True, padded=pre_padded)
+            elif pre_padded:          # (a padded frame without the streaming weights: cannot happen through the transform)
+                raise ValueError("ResNet50Body: padded space-to-depth frame without the streaming stem weights")
+            else:
+                x = ops.conv2d(x, pk["stem_s2d"], relu=True, out_hw=(x.shape[1], x.shape[2]))
         else:
             x = ops.conv2d(x, pk["stem"], relu=True)           # 7x7/s2 + FrozenBN + ReLU
         x = ops.maxpool2d(x, 3, 2, 1)

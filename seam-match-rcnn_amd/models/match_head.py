@@ -147,9 +147,10 @@ class MatchPredictor(nn.Module):
             return self.trunk_taped(x)
         dt = getattr(self, "compute_dtype", torch.float32)
         x = x.detach()
-        if (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and dt != torch.float16 and x.shape[0] > 0
-                and x.permute(0, 2, 3, 1).is_contiguous()):
-            # channels_last input (what the extractor hands out as 'roi_features'): already the kernels' NHWC layout
+        if (x.dim() == 4 and x.is_cuda and x.shape[0] > 0 and x.permute(0, 2, 3, 1).is_contiguous()
+                and ((x.dtype == torch.float32 and dt != torch.float16) or (x.dtype == torch.float16 and dt == torch.float16))):
+            # channels_last input (what the extractor hands out as 'roi_features' with roi_features_contiguous = False): already
+            # the kernels' NHWC layout, in the trunk's own precision
             return self.trunk_nhwc(x.permute(0, 2, 3, 1))
         return self.trunk_nhwc(ops.nchw_to_nhwc(x.to(torch.float32), torch.float16 if dt == torch.float16 else torch.float32))
 

@@ -37,8 +37,8 @@ class TemporalRoIHeads(nn.Module):
 
     video = True                    # emit 'roi_features' (ref :314); NewRoIHeads does not
     roi_features_contiguous = True   # 'roi_features' is a fresh contiguous NCHW tensor, as the reference returns (ref :314);
-    #                                  False: an NCHW-shaped channels_last VIEW of the RoIAlign tile (no transpose pass; opt-in for
-    #                                  pipelines whose only consumer is the aggregator, e.g. bench.py)
+    #                                  False: an NCHW-shaped channels_last VIEW of the RoIAlign tile (no transpose pass; fp16 storage on
+    #                                  the fp16 path; opt-in for pipelines whose only consumer is the aggregator, e.g. bench.py)
     nms_prefix = 4096                # candidates per image that enter the detection NMS (exactness is checked, see postprocess_detections)
     fallback_score = 0.1            # ref :252 (1.0 in models/matchrcnn.py:377)
 
@@ -210,10 +210,12 @@ class TemporalRoIHeads(nn.Module):
             # 'roi_features' [K,256,14,14] (ref :314): a contiguous NCHW copy by default (one transpose kernel).  With
             # ``roi_features_contiguous = False`` the exact-fp32 path hands out an NCHW-shaped VIEW of the NHWC tile RoIAlign wrote
             # (torch's channels_last memory format: same shape and values, no transpose pass) -- the aggregator reads that layout
-            # back without a copy; the fp16 path always converts (fp32 output).
+            # back without a copy (on the fp16 path the view is fp16; the default contiguous form is always fp32).
             roi_nchw = None
             if self.video:
-                if roi_nhwc.dtype == torch.float32 and not self.roi_features_contiguous:
+                if not self.roi_features_contiguous:
+                    # (fp16 path, round 6: the view keeps the tile's fp16 storage -- the aggregator's trunk takes it as it is; the two
+                    #  conversion passes f16 NHWC -> f32 NCHW -> f16 NHWC were 3.2 ms of a config-5 step)
                     roi_nchw = roi_nhwc.permute(0, 3, 1, 2)
                 else:
                     roi_nchw = ops.nhwc_to_nchw(roi_nhwc)

@@ -521,6 +521,33 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     return y
 
 
+def stem_s2d_f16(x: torch.Tensor, w_rows: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
+                 relu: bool = True, padded: bool = False) -> torch.Tensor:
+    """ResNet stem of the fp16 path on the space-to-depth frame ``x`` [N,H2,W2,16] (``preprocess(..., s2d=True)``) through the streaming
+    kernel (``seam_stem_s2d_swh_f16``): the frame is zero-padded (2 cells before, 1 after) so that a tap is a constant shift of the
+    flattened cell index -- ``padded=True``: ``x`` is that frame already, [N,H2+3,W2+3,16] (``preprocess(..., s2d_pad=(2, 1))``), else
+    one padding copy is made.  ``w_rows`` fp16 [64,256], k = (4 r + s) * 16 + channel.  -> NHWC [N,H2,W2,64] fp16."""
+    x = _req(x, F16, "x")
+    n, h2, w2, c = x.shape
+    if padded:
+        h2, w2 = h2 - 3, w2 - 3
+    if c != 16 or h2 < 1 or w2 < 1 or tuple(w_rows.shape) != (64, 256) or w_rows.dtype != F16:
+        raise ValueError("stem_s2d_f16: x must be [N,H2,W2,16] fp16 (padded: +3 cells per direction) and w_rows [64,256] fp16")
+    xp = x if padded else torch.nn.functional.pad(x, (0, 0, 2, 1, 2, 1))
+    y = torch.empty((n, h2, w2, 64), dtype=F16, device=x.device)
+    trace = CONV_TRACE
+    if trace is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _native.check(_native.lib().seam_stem_s2d_swh_f16(_ptr(xp), _ptr(w_rows), _ptr(scale), _ptr(shift), _ptr(y), n, h2, w2,
+                                                      1 if relu else 0, _stream()), "seam_stem_s2d_swh_f16")
+    if trace is not None:
+        e1.record()
+        trace.append(("stem_swh<4,2>", 2.0 * n * h2 * w2 * 64 * 16 * 12, e0, e1, (n, h2, w2, 16, 64, 4, 1),
+                      float(2 * (xp.numel() + w_rows.numel() + y.numel()))))
+    return y
+
+
 def conv2d_topdown(x: torch.Tensor, pc: PackedConv, top: torch.Tensor) -> torch.Tensor:
     """FPN top-down merge [TV]: conv(x) + nearest-upsample(top) -> NHWC.  Exact-fp32 weights: ONE launch (the coarse map is
     added in the conv epilogue, ``seam_conv2d_upres_f32``); other precisions: conv + ``upsample_add_``.  Both forms round
@@ -679,10 +706,12 @@ def _sfx(dtype) -> str:
     return "f32" if dtype == F32 else "f16"
 
 
-def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, wp: int, dtype=F32, s2d: bool = False) -> torch.Tensor:
+def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, wp: int, dtype=F32, s2d: bool = False,
+               s2d_pad: tuple = (0, 0)) -> torch.Tensor:
     """normalise + resize + pad + CHW->NHWC for a list of fp32 images -> [N,hp,wp,4] fp32 / [N,hp,wp,8] fp16.
     ``s2d`` (fp32 [3,H,W] images only): the space-to-depth layout [N,hp/2,wp/2,12] of ``seam_preprocess_s2d_batch_f32``
-    (fp16: [N,hp/2,wp/2,16], four zero channels, ``_f16``)."""
+    (fp16: [N,hp/2,wp/2,16], four zero channels, ``_f16``); ``s2d_pad`` = (lo, hi) (fp16 only): zero cells before / after the frame
+    in both directions -- [N, hp/2 + lo + hi, wp/2 + lo + hi, 16], the input of ``stem_s2d_f16(..., padded=True)``."""
     lib = _native.lib()
     # device check FIRST, for every image and every branch below: a CPU tensor must raise SeamNativeError, never reach a
     # kernel as a raw host pointer (the one-launch batch branches take data_ptr() of the views directly)
@@ -693,8 +722,13 @@ def preprocess(images: Sequence[torch.Tensor], sizes: Sequence[tuple], hp: int, 
         if dtype not in (F32, F16) or hp % 2 or wp % 2 or any(i.dtype != F32 or i.dim() != 3 or i.shape[0] != 3 for i in images):
             raise ValueError("preprocess(s2d=True): fp32 [3,H,W] images and an even padded size")
         n = len(images)
-        out = torch.empty((n, hp // 2, wp // 2, 12 if dtype == F32 else 16), dtype=dtype, device=images[0].device)
-        s2d_fn = lib.seam_preprocess_s2d_batch_f32 if dtype == F32 else lib.seam_preprocess_s2d_batch_f16
+        plo, phi = (int(s2d_pad[0]), int(s2d_pad[1])) if dtype == F16 else (0, 0)
+        out = torch.empty((n, hp // 2 + plo + phi, wp // 2 + plo + phi, 12 if dtype == F32 else 16), dtype=dtype, device=images[0].device)
+        if dtype == F32:
+            s2d_fn = lib.seam_preprocess_s2d_batch_f32
+        else:
+            def s2d_fn(src, stride, dst, cnt, ih, iw, oh, ow, hpp, wpp, st):
+                return lib.seam_preprocess_s2d_pad_batch_f16(src, stride, dst, cnt, ih, iw, oh, ow, hpp, wpp, plo, phi, st)
         same = n <= 65535 and all(i.shape == images[0].shape and i.is_contiguous() for i in images) \
             and all(tuple(z) == tuple(sizes[0]) for z in sizes)
         p0 = images[0].data_ptr()

@@ -434,3 +434,31 @@ def test_fpn_topdown_merge_on_the_streaming_kernel_f16(ops, shape):
         ops.SWH, ops.CONV_TRACE = saved, None
     assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
     assert float((got.float() - two.float()).abs().max()) <= 2.0 ** -8 * float(two.float().abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 21, 35), (3, 64, 50), (1, 97, 131), (2, 8, 9)])
+def test_stem_on_the_streaming_kernel_f16(ops, shape):
+    """seam_stem_s2d_swh_f16 (round 6): ResNet.conv1 + bn1 + relu on the zero-padded space-to-depth frame -- a tap is a constant
+    shift of the flattened cell index -- against the fp32 reference of the same fp16-rounded operands (the 4x4 / pad-2 convolution
+    of seam_conv2d_crop_f16's call site) and against that kernel (<= 2 fp16 ulps); repeat launches identical; an image alone == the
+    same image inside the batch; ragged sizes (tiles that straddle rows, images and the end of the frame)."""
+    d = dev()
+    n, h2, w2 = shape
+    x = rnd(780, (n, 16, h2, w2)).half().float()
+    x[:, 12:] = 0                                      # the four zero channels of the fp16 cells
+    ws = (rnd(781, (64, 12, 4, 4), "w") / math.sqrt(12 * 16)).half().float()
+    bn = (torch.from_numpy(synth.uniform(synth.stream_id(782, "bw"), (64,), 0.5, 1.5)), rnd(783, (64,), "bb") * 0.1,
+          rnd(784, (64,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(785, "rv"), (64,), 0.5, 1.5)))
+    pc = ops.pack_conv(ws.to(d), None, tuple(t.to(d) for t in bn), stride=1, pad=2, cstore=16, wino=False, dtype=H)
+    rows = F.pad(ws, (0, 0, 0, 0, 0, 4)).permute(0, 2, 3, 1).reshape(64, 256).half().contiguous().to(d)
+    xd = nhwc(x).half().to(d)
+    got = ops.stem_s2d_f16(xd, rows, pc.scale, pc.shift, relu=True)
+    assert got.dtype == H and tuple(got.shape) == (n, h2, w2, 64)
+    assert torch.equal(ops.stem_s2d_f16(xd, rows, pc.scale, pc.shift, relu=True), got)
+    assert torch.equal(ops.stem_s2d_f16(xd[n - 1:].contiguous(), rows, pc.scale, pc.shift, relu=True), got[n - 1:])
+    sc = bn[0] * (bn[3] + 1e-5).rsqrt()
+    full = F.conv2d(F.pad(x[:, :12], (2, 1, 2, 1)), ws)
+    ref = F.relu(full * sc[None, :, None, None] + (bn[1] - bn[2] * sc)[None, :, None, None])
+    assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
+    old = ops.conv2d(xd, pc, relu=True, out_hw=(h2, w2))
+    assert float((got.float() - old.float()).abs().max()) <= 2.0 ** -9 * float(old.float().abs().max())
