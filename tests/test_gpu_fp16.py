@@ -462,3 +462,20 @@ def test_stem_on_the_streaming_kernel_f16(ops, shape):
     assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
     old = ops.conv2d(xd, pc, relu=True, out_hw=(h2, w2))
     assert float((got.float() - old.float()).abs().max()) <= 2.0 ** -9 * float(old.float().abs().max())
+
+
+def test_padded_space_to_depth_frame_f16(ops):
+    """preprocess(..., s2d=True, s2d_pad=(2, 1)) (seam_preprocess_s2d_pad_batch_f16): the interior is the unpadded frame bit for
+    bit, the border cells are zero -- single-launch batch form (frames of one clip tensor) and the per-image form (ragged sizes)."""
+    d = dev()
+    clip = torch.from_numpy(synth.uniform(synth.stream_id(790, "img"), (3, 3, 60, 90))).to(d)
+    ref_sizes = [(64, 96)] * 3
+    for imgs, sizes in (([clip[i] for i in range(3)], ref_sizes),
+                        ([clip[0], clip[1, :, :50, :80].contiguous()], [(64, 96), (53, 85)])):
+        plain = ops.preprocess(imgs, sizes, 64, 96, H, s2d=True)
+        padded = ops.preprocess(imgs, sizes, 64, 96, H, s2d=True, s2d_pad=(2, 1))
+        assert tuple(padded.shape) == (len(imgs), 32 + 3, 48 + 3, 16)
+        assert torch.equal(padded[:, 2:-1, 2:-1], plain)
+        border = padded.clone()
+        border[:, 2:-1, 2:-1] = 0
+        assert float(border.float().abs().max()) == 0.0
