@@ -571,6 +571,12 @@ def main():
                            "parallelism": f"dp{world} (clips sharded; product bank all-gathered over RCCL)"
                            if world > 1 else "single GPU"},
                 "pipeline_tflops": round(FLOP_PER_CLIP * value / 1e12, 2)}
+        if not stub:
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            line["hbm_gb"] = {"allocator_peak_reserved": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
+                              "allocator_peak_allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                              "device_total": round(total_b / 2 ** 30, 1), "device_free_now": round(free_b / 2 ** 30, 1),
+                              "allocator_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0))}
         line.update(extras)
         if per_rank_ms is not None:
             line["ms_per_step_per_rank"] = per_rank_ms
