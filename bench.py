@@ -81,6 +81,12 @@ def parse():
                          "a side stream: bit-identical results, ~1.4 %% faster, but concurrent kernels stretch each other's durations -- "
                          "per-kernel profiles (rocprofv3 --stats, the PMC passes) are taken with this flag; the roofline leg always "
                          "instruments a single-stream step)")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="fp16 path only (--dtype f16): run the body on two HIP streams like the fp32 path.  The fp16 default is ONE stream: "
+                         "its persistent one-block-per-CU kernels (conv3x3_f16pc, conv1x1_swh) partition a launch's tiles statically, and "
+                         "when the other stream's kernel holds part of the CUs at launch the late blocks serialise -- observed as a bimodal "
+                         "step (157-166 ms on six boxes, 215-220 ms twice, same code; the single-stream instrumented step of those two "
+                         "runs: 157 ms); two streams are worth 2 %% when they interleave well")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the clip the CPU baseline times (default: all)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU runs after one warm-up; the minimum is reported")
     ap.add_argument("--graph", action="store_true",
@@ -282,6 +288,8 @@ def main():
     model = ta = frame_list = rois = types = ids = side = None
     if not stub:
         import seam_match_rcnn_amd.models.detection as det
+        if args.dtype == "f16" and not args.two_streams:
+            args.single_stream = True
         if args.single_stream:
             det.BODY_STREAMS, det.LEVEL_STREAMS = 1, False
         log("building synthetic weights")
