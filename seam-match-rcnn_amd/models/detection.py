@@ -82,9 +82,9 @@ class GeneralizedRCNNTransform(nn.Module):
         wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
         # fp32 / fp16 paths with float images: space-to-depth layout for the 4x4 / stride-1 form of the stem (STEM_S2D)
         s2d = STEM_S2D and cdt(self) in (torch.float32, torch.float16) and all(i.dtype == torch.float32 for i in images)
-        # fp16 path: the frame comes with the zero cells the streaming stem kernel wants around it (2 before, 1 after); the body
-        # recognises that form by its shape (hp, wp are multiples of 32, so a padded side is 3 mod 16, a plain one 0)
-        pad = (2, 1) if (s2d and STEM_SWH and adt(self) == torch.float16 and d % 32 == 0) else (0, 0)
+        # fp16 path: the frame comes with the zero cells the streaming stem kernel wants around it (2 before, 1 after); the caller
+        # tells the backbone (``s2d_padded``) by comparing the frame's height with the padded size returned here
+        pad = (2, 1) if (s2d and STEM_SWH and adt(self) == torch.float16) else (0, 0)
         return ops.preprocess(images, sizes, hp, wp, adt(self), s2d=s2d, s2d_pad=pad), sizes, orig, (hp, wp)
 
     @staticmethod
@@ -195,8 +195,9 @@ class ResNet50Body(nn.Module):
             self._pk, self._pk_key = pk, key
         return self._pk
 
-    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
-        """x NHWC4 [N,H,W,4] -> [C2, C3, C4, C5] NHWC."""
+    def forward(self, x: torch.Tensor, s2d_padded: bool = False) -> List[torch.Tensor]:
+        """x NHWC4 [N,H,W,4] (or the space-to-depth frame [N,H/2,W/2,12|16]; ``s2d_padded``: the fp16 frame with its 2 + 1 zero
+        cells around it, [N,H/2+3,W/2+3,16]) -> [C2, C3, C4, C5] NHWC."""
         pk = self.packed()
         n = x.shape[0]
         if BODY_STREAMS >= 2 and n >= 2 * BODY_STREAMS and x.is_cuda:
@@ -207,7 +208,7 @@ class ResNet50Body(nn.Module):
             if (getattr(self, "_streams", None) is None or len(self._streams) != BODY_STREAMS
                     or self._streams[0].device != x.device):            # rebuilt after model.to(another device)
                 self._streams = [torch.cuda.Stream(device=x.device) for _ in range(BODY_STREAMS)]
-            spad = 3 if (x.shape[-1] == 16 and x.shape[1] % 16 == 3 and x.shape[2] % 16 == 3) else 0      # padded s2d frame (fp16 path)
+            spad = 3 if s2d_padded else 0      # padded s2d frame (fp16 path)
             h1, w1 = ((x.shape[1] - spad, x.shape[2] - spad) if x.shape[-1] in (12, 16) else
                       ((x.shape[1] + 6 - 7) // 2 + 1, (x.shape[2] + 6 - 7) // 2 + 1))
             hh, ww = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
@@ -221,19 +222,20 @@ class ResNet50Body(nn.Module):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     lo, hi = bounds[i], bounds[i + 1]
-                    self._run(x[lo:hi], pk, [o[lo:hi] for o in outs])
+                    self._run(x[lo:hi], pk, [o[lo:hi] for o in outs], s2d_padded)
             for st in self._streams:
                 cur.wait_stream(st)
             return outs
-        return self._run(x, pk, None)
+        return self._run(x, pk, None, s2d_padded)
 
-    def _run(self, x, pk, outs):
+    def _run(self, x, pk, outs, s2d_padded=False):
         if x.shape[-1] in (12, 16):    # space-to-depth input [N,H/2,W/2,12] (fp16: 16): the stem as a 4x4 / stride-1 conv, output grid = input grid
-            pre_padded = x.shape[-1] == 16 and x.shape[1] % 16 == 3 and x.shape[2] % 16 == 3
-            if "stem_rows" in pk and x.dtype == torch.float16 and x.shape[-1] == 16:
-                x = ops.stem_s2d_f16(x, pk["stem_rows"], pk["stem_s2d"].scale, pk["stem_s2d"].shift, relu=True, padded=pre_padded)
-            elif pre_padded:          # (a padded frame without the streaming weights: cannot happen through the transform)
-                raise ValueError("ResNet50Body: padded space-to-depth frame without the streaming stem weights")
+            streaming = ("stem_rows" in pk and x.dtype == torch.float16 and x.shape[-1] == 16
+                         and (x.shape[1] - (3 if s2d_padded else 0)) * (x.shape[2] - (3 if s2d_padded else 0)) >= 128)
+            if s2d_padded and not streaming:      # (cannot happen through the transform: it pads only when the kernel will run)
+                x = x[:, 2:-1, 2:-1].contiguous()
+            if streaming:
+                x = ops.stem_s2d_f16(x, pk["stem_rows"], pk["stem_s2d"].scale, pk["stem_s2d"].shift, relu=True, padded=s2d_padded)
             else:
                 x = ops.conv2d(x, pk["stem_s2d"], relu=True, out_hw=(x.shape[1], x.shape[2]))
         else:
@@ -341,8 +343,8 @@ class BackboneWithFPN(nn.Module):
         self.fpn = FeaturePyramidNetwork()
         self.out_channels = 256
 
-    def forward(self, x):
-        return self.fpn(self.body(x))
+    def forward(self, x, s2d_padded: bool = False):
+        return self.fpn(self.body(x, s2d_padded))
 
 
 def resnet_fpn_backbone(backbone_name="resnet50", pretrained=False, **_):

@@ -276,7 +276,8 @@ class VideoMatchRCNN(nn.Module):
     # ---- stages ------------------------------------------------------------------------------------
     def extract_features(self, images: Sequence[torch.Tensor]):
         x, sizes, orig, padded = self.transform(images)
-        return self.backbone(x), sizes, orig, padded
+        s2d_padded = x.shape[-1] == 16 and x.shape[1] == padded[0] // 2 + 3        # fp16 path: zero cells around the space-to-depth frame
+        return self.backbone(x, s2d_padded), sizes, orig, padded
 
     def postprocess(self, result, sizes, orig):
         for r, sz, o in zip(result, sizes, orig):
