@@ -159,16 +159,6 @@ int seam_conv1x1_swh_f16(const void* x, const void* x2, const void* w, const flo
 int seam_stem_s2d_swh_f16(const void* xpad, const void* w, const float* scale, const float* shift, void* y, int N, int Ho, int Wo,
                           int relu, seam_stream_t stream);
 
-/* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels, fp16 (csrc/seam_pwh.hip, round 6): the conv2 layers of
- * ResNet layer1 [TV Bottleneck.conv2 behind models/video_matchrcnn.py:337] of the fp16 path as the streaming kernel above -- on the
- * dense NHWC map a tap is a constant shift of the flattened pixel index; (pixel, tap) pairs whose window leaves the image get an
- * out-of-range offset and read the zeros of the padding.  x, y fp16 [N, H, W, 64]; w fp16 [64, 576] row-major, k = (3 r + s) * 64 +
- * channel; scale / shift fp32 [64] or NULL; relu 0 | 1.  Same products as seam_conv2d_f16, fp32 accumulation in tap-major order
- * (agreement to fp32 rounding); deterministic and batch-invariant.  _supported: C == K == 64, pad 1, H * W >= 128. */
-int seam_conv3x3_c64_swh_supported(int N, int H, int W, int C, int K, int pad);
-int seam_conv3x3_c64_swh_f16(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H, int W,
-                             int relu, seam_stream_t stream);
-
 /* Pointwise (1x1, stride 1, pad 0) convolution with a LONG reduction as producer / consumer waves (csrc/seam_pwpc.hip, round 5):
  * the bottleneck reductions of ResNet layer2-4 and the layer4 expansions [TV Bottleneck conv1 / conv3 behind
  * models/video_matchrcnn.py:337], exact fp32 on v_mfma_f32_32x32x2_f32, the same contract as seam_conv2d_f32 on those shapes:

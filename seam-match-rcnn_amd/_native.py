@@ -59,8 +59,6 @@ SIGNATURES = {
     "seam_conv1x1_sw_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv1x1_swh_config": (_i, [C.c_longlong, _i, _i, _i]),
     "seam_conv1x1_swh_f16": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "seam_conv3x3_c64_swh_supported": (_i, [_i, _i, _i, _i, _i, _i]),
-    "seam_conv3x3_c64_swh_f16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "seam_stem_s2d_swh_f16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv2d_upres_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -429,166 +429,11 @@ __global__ __launch_bounds__(64 * PWH_WAVES, 1) void stem_swh_kernel(const StemA
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, fp16, as the same streaming kernel (round 6): the conv2 layers of ResNet
-// layer1 [TV Bottleneck.conv2 behind models/video_matchrcnn.py:337] on the 192 x 336 maps of the config-5 path -- one 64-channel
-// chunk, K = 64: neither conv3x3_f16pc's shape (C, K multiples of 128) nor a good one for the implicit GEMM (0.24 of the HBM roof).
-// On the DENSE NHWC map the tap (r, s) of pixel m (flattened over N * H * W) is the pixel m + (r - 1) W + (s - 1): a constant shift,
-// wrong only where the window leaves the image (first / last row or column) -- those (lane, tap) pairs are given an out-of-range
-// vector offset, so the descriptor's range check returns the zeros the padding would have held.  A wave tile = 128 consecutive
-// pixels x 64 channels; weights (64 x 576 halves, 75 KB) stationary in LDS; 36 k-steps (9 taps x 4 x 16 channels); the epilogue is
-// conv1x1_swh's (consecutive dense rows).
-struct Shift3Args {
-    const _Float16* x;     // [N, H, W, 64]
-    const _Float16* w;     // [64, 576] row-major fp16, k = (3 r + s) * 64 + channel
-    const float* scale;
-    const float* shift;
-    _Float16* y;           // [N, H, W, 64]
-    int H, W, relu;
-    long long M;           // N * H * W
-    unsigned m_W, m_H;     // ceil(2^32 / d)
-};
-
-__global__ __launch_bounds__(64 * PWH_WAVES, 1) void shift3_swh_kernel(const Shift3Args p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 4, NT = 2, NS = 64, Ct = 576, LDW = Ct * 2 + 16, RD = 4, nks = 36;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const vec = reinterpret_cast<float*>(smem + NS * LDW + PWH_WAVES * TBUF);
-    for (int v = tid; v < NS * (Ct >> 3); v += 64 * PWH_WAVES) {
-        const int r = v / (Ct >> 3), c8 = v - r * (Ct >> 3);
-        *reinterpret_cast<f32x4*>(smem + r * LDW + c8 * 16) = *reinterpret_cast<const f32x4*>(p.w + (size_t)r * Ct + c8 * 8);
-    }
-    for (int v = tid; v < NS; v += 64 * PWH_WAVES) {
-        vec[v] = p.scale ? p.scale[v] : 1.f;
-        vec[NS + v] = p.shift ? p.shift[v] : 0.f;
-    }
-    __syncthreads();
-    char* const tb = smem + NS * LDW + wid * TBUF;
-
-    const long long tiles = (p.M + 32 * MT - 1) / (32 * MT);
-    const long long wstride = (long long)gridDim.x * PWH_WAVES;
-    long long tt = (long long)blockIdx.x * PWH_WAVES + wid;
-    if (tt >= tiles) return;
-
-    const unsigned a_lane = (unsigned)((lane & 31) * 128 + (lane >> 5) * 16);
-    const int b_lane = (int)(unsigned)(size_t)(lds_char*)smem + (lane & 31) * LDW + (lane >> 5) * 16;
-    const int t_wr0 = ((lane >> 5) * 4) * 128 + ((lane & 31) >> 2) * 16 + (lane & 3) * 4;
-    const int t_wr1 = ((lane >> 5) * 4) * 128 + ((((lane & 31) >> 2)) ^ 1) * 16 + (lane & 3) * 4;
-    const int t_par = (lane >> 2) & 1;
-    const int t_rd0 = (lane >> 2) * 128 + (((lane & 3) * 2) ^ t_par) * 16;
-    const int t_rd1 = (lane >> 2) * 128 + (((lane & 3) * 2 + 1) ^ t_par) * 16;
-    const unsigned e_lane = (unsigned)((lane >> 2) * 128 + (lane & 3) * 16);
-    const float* const v_lane = vec + (lane & 3) * 8;
-
-    f16x8 ring[RD][MT];
-    long long ld_tt = tt;
-    int ld_ks = 0;
-    __amdgpu_buffer_rsrc_t ld_rs;
-    unsigned edge[MT];            // per 32-pixel group of the tile being fetched: bit 0 x == 0, 1 x == W - 1, 2 y == 0, 3 y == H - 1 (all: no pixel)
-    auto set_ld_tile = [&](long long t) {
-        // the descriptor starts W + 1 pixels BEFORE the tile (a pure address: pixels in front of the tensor are only ever named by
-        // (lane, tap) pairs whose edge bits make them out of range), so that every tap's shift is a non-negative scalar offset
-        const long long row0 = t * (32 * MT);
-        const long long first = row0 - (p.W + 1);
-        const long long left = t < tiles ? (p.M - first) * 128 : 0;
-        ld_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (t < tiles ? first : 0) * 64), 0,
-                                                  (int)(left > 0x7fffffffLL ? 0x7fffffffLL : left), 0x00020000);
-        const long long q0 = row0 / p.W;                         // wave-uniform 64-bit division, once per tile
-        const int x0 = (int)(row0 - q0 * p.W);
-        const int y0 = (int)(q0 % p.H);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int xx = x0 + 32 * i + (lane & 31);             // < W + 128
-            const int dy = (int)__umulhi((unsigned)xx, p.m_W);    // rows further down
-            const int xr = xx - dy * p.W;
-            int yr = y0 + dy;                                     // < H + 128 / W + 1
-            yr -= (int)__umulhi((unsigned)yr, p.m_H) * p.H;
-            const bool none = t >= tiles || row0 + 32 * i + (lane & 31) >= p.M;
-            edge[i] = none ? 15u : (unsigned)((xr == 0 ? 1 : 0) | (xr == p.W - 1 ? 2 : 0) | (yr == 0 ? 4 : 0) | (yr == p.H - 1 ? 8 : 0));
-        }
-    };
-    set_ld_tile(tt);
-    auto issue_a = [&](f16x8 (&slot)[MT]) {          // k-step ld_ks: tap (r, s) = ((ld_ks >> 2) / 3, (ld_ks >> 2) % 3), 16 channels (ld_ks & 3)
-        const int tap = ld_ks >> 2;
-        const int r = tap >= 6 ? 2 : tap >= 3 ? 1 : 0, s3 = tap - 3 * r;
-        const int so = (p.W + 1 + (r - 1) * p.W + (s3 - 1)) * 128 + (ld_ks & 3) * 32;
-        const unsigned bad = (r == 0 ? 4u : r == 2 ? 8u : 0u) | (s3 == 0 ? 1u : s3 == 2 ? 2u : 0u);      // wave-uniform
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const unsigned vo = (edge[i] & bad) ? 0x80000000u : a_lane;
-            slot[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(ld_rs, vo, so + i * 32 * 128, 0));
-        }
-        if (++ld_ks == nks) { ld_ks = 0; ld_tt += wstride; set_ld_tile(ld_tt); }
-    };
-#pragma unroll
-    for (int s = 0; s < RD; ++s) issue_a(ring[s]);
-
-    f32x16 acc[MT][NT];
-    f16x8 fb[NT];
-    int bj0 = b_lane;
-    constexpr int bstep = 32 * LDW;
-    auto trip = [&](int ks0, auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const bool last = ks0 + 4 >= nks;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (u == 3) bj0 += !last ? 128 : -(nks - 4) * 32;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    if (FIRST && u == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[u][i], fb[j], z, 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[u][i], fb[j], acc[i][j], 0, 0, 0);
-                    }
-                }
-                if (!(last && u == 3)) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj0 + j * bstep + (u < 3 ? (u + 1) * 32 : 0)));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            issue_a(ring[u]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    for (; tt < tiles; tt += wstride) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = __builtin_bit_cast(f16x8, lds_read16(bj0 + j * bstep));
-        trip(0, std::true_type{});
-        for (int ks0 = 4; ks0 < nks; ks0 += 4) trip(ks0, std::false_type{});
-
-        const long long row0 = tt * (32 * MT);
-        const long long rows = p.M - row0 < 32 * MT ? p.M - row0 : 32 * MT;
-        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)row0 * 64), 0, (int)(rows * 128), 0x00020000);
-        constexpr int STEPS = MT * 2 * NT;
-        auto steps = [&](auto relu_tag) {
-            constexpr bool RELU = decltype(relu_tag)::value;
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                const int ih = s / NT, i = ih >> 1, h = ih & 1, j = s % NT;
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    *reinterpret_cast<float*>(tb + ((r & 1) ? t_wr1 : t_wr0) + ((r & 3) + 8 * (r >> 2)) * 128) = acc[i][j][8 * h + r];
-                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(v_lane + 32 * j), sc1 = *reinterpret_cast<const f32x4*>(v_lane + 32 * j + 4);
-                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(v_lane + NS + 32 * j), sh1 = *reinterpret_cast<const f32x4*>(v_lane + NS + 32 * j + 4);
-                f32x4 v0 = *reinterpret_cast<const f32x4*>(tb + t_rd0) * sc0 + sh0;
-                f32x4 v1 = *reinterpret_cast<const f32x4*>(tb + t_rd1) * sc1 + sh1;
-                if constexpr (RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
-                }
-                f16x8 hv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { hv[e] = (_Float16)v0[e]; hv[e + 4] = (_Float16)v1[e]; }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), y_rsrc, e_lane + (unsigned)((16 * ih * 64 + 32 * j) * 2), 0, 0);
-            }
-        };
-        if (p.relu) steps(std::true_type{});
-        else steps(std::false_type{});
-    }
-}
+// (Round 6, null result: the same flattened-shift form for the 3x3 / 64 -> 64 layers of layer1 on the dense map -- a tap is a constant
+// shift of the flattened pixel index, windows that leave the image get an out-of-range offset -- was built, bit-identical to the
+// implicit GEMM, and 0.81x its speed (profiles/r06_shift3_ab.txt: 3 015 vs 2 443 us at 240 x 192 x 336): with 128-byte cells a wave's
+// A-fragment load touches 32 cache lines for 32 bytes each (the stem's 32-byte cells: one contiguous KB), four times the work in the
+// texture addresser.  Removed; those layers need their patch staged through LDS like conv3x3_f16pc.)
 
 // 0 = not served by this kernel (the caller stays on the implicit GEMM); otherwise MT * 100 + NT
 inline int pwh_config(long long M, int C1, int C2, int K) {
@@ -705,39 +550,6 @@ int seam_stem_s2d_swh_f16(const void* xpad, const void* w, const float* scale, c
         attr_done.fetch_or(1u << (dev_ & 31), std::memory_order_release);
     }
     hipLaunchKernelGGL(stem_swh_kernel, dim3((unsigned)nblk), dim3(64 * PWH_WAVES), lds, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-}
-
-// 3x3 / stride 1 / pad 1, 64 -> 64 channels, fp16 operands / fp32 accumulate [TV Bottleneck.conv2 of ResNet layer1]: x, y fp16 NHWC
-// [N, H, W, 64]; w fp16 [64, 576] row-major with k = (3 r + s) * 64 + channel; scale / shift fp32 [64] or NULL.  Same products as
-// seam_conv2d_f16, fp32 accumulation in tap-major order; deterministic, batch-invariant.  1 when the shape is served.
-int seam_conv3x3_c64_swh_supported(int N, int H, int W, int C, int K, int pad) {
-    return (N > 0 && H >= 2 && W >= 2 && C == 64 && K == 64 && pad == 1 && (long long)H * W >= 128 && (long long)W + 2 < (1 << 22) &&
-            (long long)H + 130 < (1ll << 31) / (W > H ? W : H)) ? 1 : 0;
-}
-
-int seam_conv3x3_c64_swh_f16(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H, int W,
-                             int relu, void* stream) {
-    if (!seam_conv3x3_c64_swh_supported(N, H, W, 64, 64, 1) || relu < 0 || relu > 1) return (int)hipErrorInvalidValue;
-    Shift3Args a;
-    a.x = (const _Float16*)x; a.w = (const _Float16*)w; a.scale = scale; a.shift = shift; a.y = (_Float16*)y;
-    a.H = H; a.W = W; a.relu = relu;
-    a.M = (long long)N * H * W;
-    a.m_W = (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W);
-    a.m_H = (unsigned)(((1ull << 32) + (unsigned)H - 1) / (unsigned)H);
-    const size_t lds = (size_t)64 * (576 * 2 + 16) + PWH_WAVES * TBUF + 2 * 64 * 4;
-    const long long tiles = (a.M + 127) / 128;
-    long long nblk = (tiles + PWH_WAVES - 1) / PWH_WAVES;
-    if (nblk > 256) nblk = 256;
-    static std::atomic<unsigned> attr_done{0};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    if (!(attr_done.load(std::memory_order_acquire) & (1u << (dev_ & 31)))) {
-        const hipError_t e = hipFuncSetAttribute((const void*)shift3_swh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        if (e != hipSuccess) return (int)e;
-        attr_done.fetch_or(1u << (dev_ & 31), std::memory_order_release);
-    }
-    hipLaunchKernelGGL(shift3_swh_kernel, dim3((unsigned)nblk), dim3(64 * PWH_WAVES), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -64,8 +64,7 @@ class PackedConv:
     shift_sw: Optional[torch.Tensor] = None   # ... and its shift vector (zeros when the layer has none)
     wq: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C >= 256 (a multiple of 128), K % 128 == 0: fragment-order weights of seam_conv1x1_pc_f32
     wh: Optional[torch.Tensor] = None   # fp16 stride-1 3x3 layers (C, K multiples of 128): fragment-order weights of seam_conv3x3_f16pc
-    wsh: Optional[torch.Tensor] = None  # fp16 1x1 / stride-1 layers (C multiple of 64, <= 512): row-major fp16 [K, C] weights of seam_conv1x1_swh_f16;
-    #                                     fp16 3x3 / stride-1 / pad-1 layers with C = K = 64: [64, 576] rows (tap-major) of seam_conv3x3_c64_swh_f16
+    wsh: Optional[torch.Tensor] = None  # fp16 1x1 / stride-1 layers (C multiple of 64, <= 512): row-major fp16 [K, C] weights of seam_conv1x1_swh_f16
 
 
 BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
@@ -261,8 +260,6 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         _native.check(lib.seam_pack_conv1x1_pc_f32(_ptr(weight.reshape(K, cin).to(F32).contiguous()), _ptr(wq), K, cs, _stream()),
                       "seam_pack_conv1x1_pc_f32")
     wsh = None
-    if SWH and dtype == F16 and mode == 0 and R == 3 and S == 3 and stride == 1 and pad == 1 and cs == cin == 64 and K == 64:
-        wsh = weight.permute(0, 2, 3, 1).reshape(64, 576).to(F16).contiguous()       # k = (3 r + s) * 64 + channel
     if (SWH and dtype == F16 and mode in (0, 1) and not is_linear and R == 1 and S == 1 and stride == 1 and pad == 0 and cs == cin
             and lib.seam_conv1x1_swh_config(1 << 20, cs, 0, K)):
         wm = weight.permute(2, 3, 1, 0).reshape(K, cin) if transposed2x2 else weight.reshape(K, cin)
@@ -456,13 +453,8 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     f16pc = (pc.dtype == F16 and pc.wh is not None and F16PC and residual is None and out_hw is None and not out_f32 and relu in (0, 1, False, True)
              and (lib.seam_conv3x3_f16pc_pays if F16PC_RULE else lib.seam_conv3x3_f16pc_supported)(n, h, w, c, pc.K, pc.pad) == 1)
     swh = (pc.dtype == F16 and pc.wsh is not None and SWH and out_hw is None and not out_f32 and h * w >= SW_MIN_HW
-           and relu in (0, 1, False, True) and pc.R == 1)
-    shift3 = (pc.dtype == F16 and pc.wsh is not None and SWH and pc.R == 3 and out_hw is None and not out_f32 and residual is None
-              and relu in (0, 1, False, True) and lib.seam_conv3x3_c64_swh_supported(n, h, w, c, pc.K, pc.pad) == 1)
-    if shift3:
-        _native.check(lib.seam_conv3x3_c64_swh_f16(_ptr(x), _ptr(pc.wsh), _ptr(pc.scale), _ptr(pc.shift), _ptr(y), n, h, w,
-                                                   1 if relu else 0, _stream()), "seam_conv3x3_c64_swh_f16")
-    elif swh:
+           and relu in (0, 1, False, True))
+    if swh:
         _native.check(lib.seam_conv1x1_swh_f16(_ptr(x), None, _ptr(pc.wsh), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                                n * h * w, c, 0, pc.K, 1 if relu else 0, 1 if residual is not None else 0, 0, 0, 0, 0,
                                                _stream()), "seam_conv1x1_swh_f16")
@@ -502,9 +494,7 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     if trace is not None:
         e1.record()
         tile = lib.seam_conv_tile_taps(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K, pc.R * pc.S)
-        if shift3:
-            variant = "conv3x3_c64_swh<4,2>"
-        elif swh:
+        if swh:
             variant = _swh_variant(lib, n * h * w, c, pc.K)
         elif narrow:
             variant = "linear_narrow"

@@ -479,32 +479,3 @@ def test_padded_space_to_depth_frame_f16(ops):
         border = padded.clone()
         border[:, 2:-1, 2:-1] = 0
         assert float(border.float().abs().max()) == 0.0
-
-
-@pytest.mark.parametrize("case", [(2, 21, 35, True, True), (3, 64, 50, True, False), (1, 97, 131, False, True), (5, 14, 14, True, True),
-                                  (2, 12, 11, True, False)])
-def test_conv3x3_c64_on_the_streaming_kernel_f16(ops, case):
-    """seam_conv3x3_c64_swh_f16 (round 6): 3x3 / pad 1, 64 -> 64 channels, on the dense map -- a tap is a constant shift of the
-    flattened pixel index, windows that leave the image read zeros through the descriptor's range check -- against the fp32
-    convolution of the same fp16-rounded operands and against conv_igemm<_Float16> (<= 2 fp16 ulps); repeat launches identical; an
-    image alone == the same image inside the batch; ragged sizes (tiles that straddle rows, images, the first and the last pixel)."""
-    d = dev()
-    n, hh, ww, relu, bn = case
-    x, wt, b, pc = _f16pc_case(ops, 800, n, 64, hh, ww, 64, 1, relu, bn)
-    assert pc.wsh is not None and tuple(pc.wsh.shape) == (64, 576)
-    ref = _f16pc_ref(x, wt, b, pc, 1, relu, bn)
-    xd = nhwc(x).half().to(d)
-    saved, ops.CONV_TRACE = ops.SWH, []
-    try:
-        ops.SWH = True
-        got = ops.conv2d(xd, pc, relu)
-        assert ops.CONV_TRACE[0][0].startswith("conv3x3_c64_swh"), ops.CONV_TRACE[0][0]
-        ops.CONV_TRACE = None
-        assert torch.equal(ops.conv2d(xd, pc, relu), got)
-        assert torch.equal(ops.conv2d(xd[n - 1:].contiguous(), pc, relu), got[n - 1:])
-        ops.SWH = False
-        other = ops.conv2d(xd, pc, relu)
-    finally:
-        ops.SWH, ops.CONV_TRACE = saved, None
-    assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
-    assert float((got.float() - other.float()).abs().max()) <= 2.0 ** -9 * float(other.float().abs().max())
