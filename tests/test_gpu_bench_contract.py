@@ -105,3 +105,26 @@ def test_more_gpus_than_the_box_has_is_a_clean_error():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "64", "--steps", "1"], cwd=ROOT, capture_output=True, text=True,
                        timeout=300, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
     assert r.returncode == 2 and "only" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bank_rows_do_not_depend_on_the_shard_split():
+    """bench.py's shop-side bank (round 6: every rank runs the shop images of ITS rows through the extractor): a row is the same bits
+    whichever rank computes it -- rows [0, 300) in one piece == [0, 100) + [100, 300) (shard borders that cut through the 128-image
+    batches) == eight ragged shards; and the rows are the aggregator's shop descriptors of the synthetic shop images."""
+    import torch
+    import bench
+    from seam_match_rcnn_amd import retrieval
+    dev = torch.device("cuda:0")
+    model, _ = bench.build_model(dev)
+    model.roi_heads.roi_features_contiguous = False
+    ta = model.roi_heads.temporal_aggregator
+    whole = bench.compute_bank_rows(model, ta, 0, 300, dev)
+    assert tuple(whole.shape) == (300, 256) and bool(torch.isfinite(whole).all())
+    two = torch.cat([bench.compute_bank_rows(model, ta, 0, 100, dev), bench.compute_bank_rows(model, ta, 100, 300, dev)])
+    assert torch.equal(two, whole)
+    parts = [bench.compute_bank_rows(model, ta, *retrieval.shard_range(300, r, 8), dev) for r in range(8)]
+    assert torch.equal(torch.cat(parts), whole)
+    assert (model.transform.min_size, model.transform.max_size) == (800, 1333)            # the shop pass restores the transform
+    # products differ: no two of the first rows are (nearly) the same descriptor
+    d = torch.cdist(whole[:64], whole[:64]) + torch.eye(64, device=dev) * 1e9
+    assert float(d.min()) > 1e-3 * float(whole.abs().max())
