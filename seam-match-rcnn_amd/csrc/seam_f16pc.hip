@@ -435,6 +435,246 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
     }
 }
 
+// =====================================================================================================================
+// conv3x3_f16pc64 (round 6): C = 64 -> K = 64 (the three 3x3 layers of layer1) -- a tile is ONE 64-channel chunk, so the chunk
+// pipeline above has nothing to run ahead on, and the layer is bound by memory (32 KiB in + 32 KiB out per 144 MFMAs of a
+// wave), not by the matrix pipe.  Same roles, other proportions:
+//   * a tile is 16 x 16 outputs (an 18 x 18 patch: 27 % halo against 33 % for 8 x 32, and the config-5 map -- 192 x 336 -- tiles
+//     exactly: 8 x 32 tiles leave 4.5 % of every launch's MFMAs on columns that do not exist);
+//   * the WEIGHTS ARE STATIONARY IN REGISTERS: consumer wave w owns output channels 32 (w & 1) .. + 31 for the pixel rows
+//     8 (w >> 1) .. + 7 of the tile; its 36 B fragments (9 taps x 4 k-steps x 16 bytes per lane = 144 registers)
+//     are loaded once per launch; 64 accumulators; the K loop is 144 MFMAs + 144 ds_read_b128 and nothing else;
+//   * the producers keep two tiles' patches in flight in registers and one ahead in LDS (patch[2]), and drain the finished tile
+//     (its own 32 KiB LDS region) beside the next tile's MFMAs;
+//   * ONE barrier per tile (behind the consumers' epilogue); that the producers have taken tile k - 1 out of the exchange region
+//     before the consumers put tile k into it is a count in LDS (it is always there long before: the drain is 8 loads + 8 stores
+//     per producer thread at the start of a 4608-cycle interval).
+// =====================================================================================================================
+#ifndef SEAM_F16PC64_ABL
+#define SEAM_F16PC64_ABL 0   // experiments (results are garbage): 1 no in-loop A reads, 2 no epilogue, 4 no patch requests, 8 no drain stores, 16 no MFMAs, 32 no patch LDS stores
+#endif
+constexpr int PB64 = 46 * 1024;                 // patch buffer: 18 x 18 pixels x 144 bytes + the dump row
+constexpr int ROWP64 = 18 * 9;                  // LDS pitch of a patch row in 16-byte slots
+constexpr int OUT64 = 2 * PB64;                 // the finished fp16 tile: 256 pixels x 128 bytes
+constexpr int SS64 = OUT64 + 32768;             // scale[64] | shift[64] fp32
+constexpr int DC64 = SS64 + 512;                // the producers' drain count
+constexpr int LDS64 = DC64 + 16;
+static_assert(324 * PXB + 128 <= PB64 && LDS64 <= 160 * 1024, "LDS map (C = 64 form)");
+__device__ __forceinline__ F16Geo f16_geo64(const F16Args& p, const int tm) {
+    F16Geo g;
+    const int img = fdivu(tm, p.per_img, p.m_per_img);
+    const int rb = tm - img * p.per_img;
+    const int byi = fdivu(rb, p.bx, p.m_bx);
+    g.tn = 0; g.img0 = img; g.n_here = 1;
+    g.y0 = byi * 16; g.x0 = (rb - byi * p.bx) * 16;
+    return g;
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_f16pc64(const F16Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    constexpr int ROWP = ROWP64;
+
+    const int T = p.total_tiles, G = gridDim.x;
+    const int xcd = blockIdx.x & 7, sl0 = blockIdx.x >> 3;
+    const int q8 = T >> 3, rem8 = T & 7;
+    const int cnt = q8 + (xcd < rem8 ? 1 : 0);
+    const int start = xcd < rem8 ? xcd * (q8 + 1) : rem8 * (q8 + 1) + (xcd - rem8) * q8;
+    const int S = (G >> 3) + ((G & 7) > xcd ? 1 : 0);
+    const int ntiles = sl0 < cnt ? (cnt - sl0 + S - 1) / S : 0;
+    if (ntiles == 0) return;
+    const int tile0 = start + sl0;
+    const size_t img_bytes = (size_t)p.H * p.W * 64 * 2;
+    const size_t out_img = (size_t)p.Ho * p.Wo * 64 * 2;
+    LDSQ unsigned* const dcnt = reinterpret_cast<LDSQ unsigned*>((LDSQ char*)smem + DC64);
+
+    if (!consumer) {
+        // =================================================== producer ===================================================
+        const int ptid = tid - 256;
+        unsigned goff[NP];
+        LDSQ char* lp[NP];
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int pix = (ptid >> 3) + 32 * r;
+            const int iy = fdivu(pix, 18, p.m_PWi);
+            const int ix = pix - iy * 18;
+            lp[r] = (LDSQ char*)smem + (pix < 324 ? (iy * ROWP + ix * 9) * 16 : PB64 - 128) + (ptid & 7) * 16;
+        }
+        auto setup = [&](const F16Geo& q) {
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                const int pix = (ptid >> 3) + 32 * r;
+                const int iy = fdivu(pix, 18, p.m_PWi);
+                const int ix = pix - iy * 18;
+                const int gy = q.y0 + iy - p.pad, gx = q.x0 + ix - p.pad;
+                const bool inb = pix < 324 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                goff[r] = inb ? (unsigned)(__mul24(__mul24(gy, p.W) + gx, 64) * 2 + (ptid & 7) * 16) : kOob;
+            }
+        };
+        f32x4 rq[2][NP];                        // two tiles' patches in registers (tile parity)
+        int tile = tile0, tiles_left = ntiles;  // the tile the REQUEST stage is at
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
+        // Every interval issues the SAME vector-memory instructions in the same order (8 stores of the drain, 11 loads of the
+        // request; without a tile they carry out-of-range offsets and touch nothing), so that hipcc's vmcnt bookkeeping is exact:
+        // with conditional requests it merged the paths and waited for the patch requested ONE interval ago -- half the distance.
+        auto request = [&](f32x4 (&dst)[NP]) {
+            if (tiles_left > 0) {
+                const F16Geo q = f16_geo64(p, tile);
+                setup(q);
+                rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + (size_t)q.img0 * img_bytes), 0, (int)img_bytes, 0x00020000);
+                tile += S;
+                --tiles_left;
+            } else {
+#pragma unroll
+                for (int r = 0; r < NP; ++r) goff[r] = kOob;
+            }
+#pragma unroll
+            for (int r = 0; r < NP; ++r)
+                dst[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (SEAM_F16PC64_ABL & 4) ? kOob : goff[r], 0, 0));
+        };
+        auto store_patch = [&](const f32x4 (&src)[NP], const int buf) {
+            if (SEAM_F16PC64_ABL & 32) return;
+#pragma unroll
+            for (int r = 0; r < NP; ++r)
+                *reinterpret_cast<f32x4 LDSQ*>(lp[r] + buf * PB64) = src[r];
+        };
+        auto drain = [&](const int k) {         // the finished tile k: LDS -> memory, 128 contiguous bytes per pixel (k < 0: nothing is stored)
+            const F16Geo qe = f16_geo64(p, tile0 + max(k, 0) * S);
+            const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((char*)p.y + (size_t)qe.img0 * out_img), 0, (int)out_img, 0x00020000);
+            const int piece = ptid & 7, ob = ptid >> 3;
+            const int sw = (ob >> 1) & 7;
+            const bool hs = (ob >> 4) & 1;
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                v[i] = *reinterpret_cast<const u32x4 LDSQ*>((LDSQ char*)smem + OUT64 + (32 * i + ob) * 128 + ((piece ^ sw) << 4));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {     // row o = 32 i + ob of the exchange region = output (2 i + (ob >> 4), ob & 15) of the tile
+                const int gy = qe.y0 + 2 * i + (ob >> 4), gx = qe.x0 + (ob & 15);
+                const bool ok = k >= 0 && gy < p.Ho && gx < p.Wo && !(SEAM_F16PC64_ABL & 8);
+                const unsigned off = ok ? (unsigned)(__mul24(__mul24(gy, p.Wo) + gx, 64) + piece * 8) * 2u : kOob;
+                const u32x4 w = hs ? u32x4{v[i][2], v[i][3], v[i][0], v[i][1]} : v[i];
+                __builtin_amdgcn_raw_buffer_store_b128(w, y_rsrc, off, 0, 0);
+            }
+            // the rows are in registers: the consumers may put the next tile over them (interval k + 1 brings the count to 4 (k + 2))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(dcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if (ptid == 0) *dcnt = 0u;
+        if (ptid < 32) {                        // the epilogue vectors (one n-tile: the same for every tile of the launch)
+            const float* src = ptid < 16 ? p.scale : p.shift;
+            const float dflt = ptid < 16 ? 1.f : 0.f;
+            const f32x4 vv = src ? *reinterpret_cast<const f32x4*>(src + (ptid & 15) * 4) : f32x4{dflt, dflt, dflt, dflt};
+            *reinterpret_cast<f32x4 LDSQ*>((LDSQ char*)smem + SS64 + ptid * 16) = vv;
+        }
+        request(rq[0]);                         // tile 0
+        request(rq[1]);                         // tile 1
+        store_patch(rq[0], 0);
+        request(rq[0]);                         // tile 2
+        F16_BAR();                              // P: tile 0's patch, the epilogue vectors and the count are visible
+        // interval k (the consumers multiply tile k out of patch[k & 1]): tile k - 1 out of the exchange region; tile k + 1
+        // registers -> patch[(k + 1) & 1]; request tile k + 3 into the freed registers; barrier
+        drain(-1);
+        store_patch(rq[1], 1);
+        request(rq[1]);
+        F16_BAR();                              // E(0)
+        for (int k = 1; k < ntiles; k += 2) {
+            drain(k - 1);
+            store_patch(rq[0], 0);              // (past the last tile: zeros into a buffer nobody reads)
+            request(rq[0]);
+            F16_BAR();                          // E(k)
+            if (k + 1 >= ntiles) break;
+            drain(k);
+            store_patch(rq[1], 1);
+            request(rq[1]);
+            F16_BAR();                          // E(k + 1)
+        }
+        drain(ntiles - 1);
+    } else {
+        // =================================================== consumer ===================================================
+        const int wn = wave & 1, ph = wave >> 1;
+        f32x4 bf[36];                           // this wave's weights: 32 channels x 64 x 9, for the whole launch
+        {
+            const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w + (size_t)wn * 36 * 1024), 0, 36 * 1024, 0x00020000);
+#pragma unroll
+            for (int s = 0; s < 36; ++s)
+                bf[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, lane * 16, s * 1024, 0));
+        }
+        // pixel group m of the wave = tile rows 8 ph + 2 m, + 1 (16 lanes each): the lane's pixel at tap (0, 0), k-half lane >> 5, in
+        // patch[0]; groups and taps are immediates
+        LDSQ char* const ab0 = (LDSQ char*)smem + ((8 * ph + ((lane >> 4) & 1)) * ROWP + (lane & 15) * 9) * 16 + (lane >> 5) * 16;
+        f32x16 acc[4];
+        f32x4 af[4];
+        F16_BAR();                              // P
+        for (int k = 0; k < ntiles; ++k) {
+            LDSQ char* const ac = ab0 + (k & 1) * PB64;
+            auto read_a = [&](const int m, const int st) -> f32x4 {
+                return *reinterpret_cast<const f32x4 LDSQ*>(ac + ((2 * m + (st >> 2) / 3) * ROWP + ((st >> 2) % 3) * 9) * 16 + (st & 3) * 32);
+            };
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = read_a(m, 0);
+#pragma unroll
+            for (int st = 0; st < 36; ++st) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    SB();
+                    if (st == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[st]), __builtin_bit_cast(f16x8, af[m]), z, 0, 0, 0);
+                    } else if ((SEAM_F16PC64_ABL & 16) && st > 1) {
+                    } else {
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[st]), __builtin_bit_cast(f16x8, af[m]), acc[m], 0, 0, 0);
+                    }
+                    SB();
+                    if (st + 1 < 36 && !(SEAM_F16PC64_ABL & 1)) af[m] = read_a(m, st + 1);
+                }
+            }
+            SB();
+            // ---- epilogue: fp32 scale / shift, fp16 rounding, ReLU; 8-byte swizzled writes of the lane's pixels into the exchange region ----
+            {
+                const unsigned want = 4u * (unsigned)(k + 1);       // interval k's drain (of tile k - 1; interval 0: an empty one) is through
+                while (__hip_atomic_load(dcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+            }
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const int h = lane >> 5, ol = lane & 31;
+            // row o = 32 (4 ph + m) + ol: 8 pieces of 16 bytes at piece ^ ((o >> 1) & 7); rows with bit 4 set swap a piece's halves
+            LDSQ char* const row0 = (LDSQ char*)smem + OUT64 + (128 * ph + ol) * 128 + (((h ^ (ol >> 4)) & 1) << 3);
+            const int sw = (ol >> 1) & 7;
+            auto finish_tile = [&](auto relu_c) {
+                constexpr bool RELU = decltype(relu_c)::value;
+                const f16x2 lo = f16x2{(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4 LDSQ*>((LDSQ char*)smem + SS64 + (wn * 32 + 8 * qd + 4 * h) * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 LDSQ*>((LDSQ char*)smem + SS64 + 256 + (wn * 32 + 8 * qd + 4 * h) * 4);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const f32x2 a0 = f32x2{acc[m][4 * qd], acc[m][4 * qd + 1]} * f32x2{sc[0], sc[1]} + f32x2{sh[0], sh[1]};
+                        const f32x2 a1 = f32x2{acc[m][4 * qd + 2], acc[m][4 * qd + 3]} * f32x2{sc[2], sc[3]} + f32x2{sh[2], sh[3]};
+                        f16x2 h0 = __builtin_convertvector(a0, f16x2), h1 = __builtin_convertvector(a1, f16x2);
+                        if (RELU) {
+                            h0 = __builtin_elementwise_max(h0, lo);
+                            h1 = __builtin_elementwise_max(h1, lo);
+                        }
+                        u32x2 pk;
+                        pk[0] = __builtin_bit_cast(unsigned, h0);
+                        pk[1] = __builtin_bit_cast(unsigned, h1);
+                        *reinterpret_cast<u32x2 LDSQ*>(row0 + m * 32 * 128 + (((wn * 4 + qd) ^ sw) << 4)) = pk;
+                    }
+                }
+            };
+            if (SEAM_F16PC64_ABL & 2) { if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 123456.75f) *reinterpret_cast<float LDSQ*>(row0) = 1.f; }
+            else if (p.relu) finish_tile(std::true_type{}); else finish_tile(std::false_type{});
+            F16_BAR();                          // E(k)
+        }
+    }
+}
+
 // OIHW fp32 [K, Cin, 3, 3] -> fp16 fragments [K/128][4][Cs/64][9][4][64][8]:
 //   element (tn, w, chunk, tap, ks, lane, e) = W[n = 128 tn + 32 w + (lane & 31)][c = 64 chunk + 16 ks + 8 (lane >> 5) + e][tap / 3][tap % 3]
 __global__ void f16pc_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int K, int Cin, int Cs) {
@@ -461,13 +701,15 @@ inline unsigned magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (
 
 // fills `a` for a supported shape; 0 = supported
 int f16pc_plan(F16Args& a, int N, int H, int W, int C, int K, int pad) {
-    if (N <= 0 || C < 64 || (C % 64) || K < 128 || (K % 128) || pad < 0 || pad > 1) return 1;
+    const bool c64 = C == 64 && K == 64;          // conv3x3_f16pc64: one chunk, one n-tile, large maps only
+    if (N <= 0 || C < 64 || (C % 64) || ((K < 128 || (K % 128)) && !c64) || pad < 0 || pad > 1) return 1;
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.pad = pad;
     a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
     if (a.Ho <= 0 || a.Wo <= 0) return 1;
-    a.tiles_n = K / 128;
+    a.tiles_n = c64 ? 1 : K / 128;
     a.nchunks = C / 64;
-    if (a.nchunks & 1) return 1;
+    if ((a.nchunks & 1) && !c64) return 1;
+    if (c64 && a.Wo <= 16 && a.Ho <= 16) return 1;
     if (a.Wo <= 16 && a.Ho <= 16) {
         a.mode = 1;
         a.PWi = a.Wo + 2; a.PHi = a.Ho + 2;
@@ -488,6 +730,7 @@ int f16pc_plan(F16Args& a, int N, int H, int W, int C, int K, int pad) {
         a.mode = 0; a.G = 1;
         a.PWi = 34; a.PHi = 10; a.npix = 340; a.imgp = 10 * f16_rowp(34);
         a.bx = (a.Wo + 31) / 32; a.by = (a.Ho + 7) / 8;
+        if (c64) { a.PWi = 18; a.PHi = 18; a.npix = 324; a.imgp = 18 * ROWP64; a.bx = (a.Wo + 15) / 16; a.by = (a.Ho + 15) / 16; }
         a.per_img = a.bx * a.by;
         a.tiles_m = N * a.per_img;
         if ((size_t)H * W * C * 2 >= kOob || (size_t)a.Ho * a.Wo * K * 2 >= kOob) return 1;
@@ -529,11 +772,31 @@ int f16pc_launch(const F16Args& a, hipStream_t st) {
 #endif
 }
 
+int f16pc64_launch(const F16Args& a, hipStream_t st) {
+    static std::atomic<unsigned> attr_done{0};
+    static std::atomic<int> cus[32];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_f16pc64, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+        if (e != hipSuccess) return (int)e;
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        cus[dev & 31].store(ncu, std::memory_order_relaxed);
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    const int ncu = cus[dev & 31].load(std::memory_order_relaxed);
+    const unsigned grid = (unsigned)(a.total_tiles > ncu ? ncu : a.total_tiles);
+    hipLaunchKernelGGL(conv3x3_f16pc64, dim3(grid), dim3(512), LDS64, st, a);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
 
-/* 1 when seam_conv3x3_f16pc takes this layer shape (3x3, stride 1, pad 0 | 1, C a multiple of 128, K a multiple of 128, maps of
+/* 1 when seam_conv3x3_f16pc takes this layer shape (3x3, stride 1, pad 0 | 1, C a multiple of 128 and K a multiple of 128 -- or C = K = 64 on maps of >= 24 output columns --, maps of
  * >= 24 output columns or whole maps of <= 16 x 16 outputs with 16 / 14 / 12 / 10 / 8 input columns), else 0 */
 int seam_conv3x3_f16pc_supported(int N, int H, int W, int C, int K, int pad) {
     F16Args a;
@@ -554,7 +817,7 @@ int seam_conv3x3_f16pc_pays(int N, int H, int W, int C, int K, int pad) {
 long long seam_f16pc_weight_halves(int K, int Cstore) { return (long long)K * Cstore * 9; }
 
 int seam_pack_conv_weight_f16pc(const float* w, void* w_packed, int K, int Cin, int Cstore, void* stream) {
-    if (K % 128 || Cstore % 64 || Cin > Cstore) return (int)hipErrorInvalidValue;
+    if ((K % 128 && !(K == 64 && Cstore == 64)) || Cstore % 64 || Cin > Cstore) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)(K / 32) * (Cstore / 64) * 36 * 64;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
@@ -569,6 +832,7 @@ int seam_conv3x3_f16pc(const void* x, const void* w_packed, const float* scale, 
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y; a.relu = relu;
     a.trace = nullptr;
     hipStream_t st = (hipStream_t)stream;
+    if (a.K == 64) return f16pc64_launch(a, st);
     switch (a.PWi) {
         case 34: return f16pc_launch<34>(a, st);
         case 16: return f16pc_launch<16>(a, st);

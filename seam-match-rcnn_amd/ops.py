@@ -63,7 +63,7 @@ class PackedConv:
     ws: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C <= 256: row-major [K, C] weights (scale folded) of seam_conv1x1_sw_f32
     shift_sw: Optional[torch.Tensor] = None   # ... and its shift vector (zeros when the layer has none)
     wq: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C >= 256 (a multiple of 128), K % 128 == 0: fragment-order weights of seam_conv1x1_pc_f32
-    wh: Optional[torch.Tensor] = None   # fp16 stride-1 3x3 layers (C, K multiples of 128): fragment-order weights of seam_conv3x3_f16pc
+    wh: Optional[torch.Tensor] = None   # fp16 stride-1 3x3 layers (C, K multiples of 128, or C = K = 64): fragment-order weights of seam_conv3x3_f16pc
     wsh: Optional[torch.Tensor] = None  # fp16 1x1 / stride-1 layers (C multiple of 64, <= 512): row-major fp16 [K, C] weights of seam_conv1x1_swh_f16
 
 
@@ -77,6 +77,7 @@ WINOGRAD = _os.environ.get("SEAM_WINOGRAD", "1") != "0"
 # fp16 path: the stride-1 3x3 layers with C, K multiples of 128 through the producer / consumer kernel (csrc/seam_f16pc.hip);
 # SEAM_F16PC=0 keeps them on the implicit GEMM
 F16PC = _os.environ.get("SEAM_F16PC", "1") != "0"
+F16PC64 = _os.environ.get("SEAM_F16PC64", "1") != "0"      # the C = K = 64 form (layer1's 3x3 layers; A/B switch)
 # exact-fp32 path: the long-reduction 1x1 layers (C >= 256, a multiple of 128; K a multiple of 128) through the producer / consumer
 # pointwise kernel (csrc/seam_pwpc.hip); SEAM_PWPC=0 keeps them on the implicit GEMM.  Layers the weights-stationary kernel takes
 # (C <= 256) stay there.
@@ -223,7 +224,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
         wp = torch.empty((rows, kred), dtype=F16, device=weight.device)
         _native.check(lib.seam_pack_conv_weight_f16(_ptr(weight), _ptr(wp), K, cin, R, S, cs, mode, _stream()),
                       "seam_pack_conv_weight_f16")
-        if F16PC and mode == 0 and R == 3 and S == 3 and stride == 1 and pad in (0, 1) and cs % 128 == 0 and K % 128 == 0:
+        if F16PC and mode == 0 and R == 3 and S == 3 and stride == 1 and pad in (0, 1) and ((cs % 128 == 0 and K % 128 == 0) or (cs == 64 and K == 64 and F16PC64)):
             wh = torch.empty((int(lib.seam_f16pc_weight_halves(K, cs)),), dtype=F16, device=weight.device)
             _native.check(lib.seam_pack_conv_weight_f16pc(_ptr(weight), _ptr(wh), K, cin, cs, _stream()), "seam_pack_conv_weight_f16pc")
     scale = shift = None

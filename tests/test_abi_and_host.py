@@ -66,10 +66,12 @@ def test_host_helpers_no_gpu(native):
     # the fp16 producer / consumer 3x3 kernel: shapes it takes, and the dispatch rule (tiles >= 3/4 full, a function of the map only)
     sup, pays = lib.seam_conv3x3_f16pc_supported, lib.seam_conv3x3_f16pc_pays
     assert sup(48, 192, 336, 256, 256, 1) == 1 and sup(1536, 14, 14, 256, 256, 1) == 1 and sup(1536, 8, 8, 256, 1024, 0) == 1
-    assert sup(48, 192, 336, 64, 64, 1) == 0 and sup(48, 192, 336, 256, 192, 1) == 0 and sup(48, 20, 20, 256, 256, 1) == 0
+    assert sup(48, 192, 336, 256, 192, 1) == 0 and sup(48, 20, 20, 256, 256, 1) == 0
+    # round 6: C = K = 64 (layer1's 3x3 layers) on large maps; no other 64-channel combination, no small maps
+    assert sup(48, 192, 336, 64, 64, 1) == 1 and sup(48, 192, 336, 64, 128, 1) == 0 and sup(48, 192, 336, 128, 64, 1) == 0 and sup(48, 14, 14, 64, 64, 1) == 0
     assert sup(48, 192, 336, 256, 256, 2) == 0 and sup(4, 2, 2, 256, 256, 0) == 0
     assert pays(48, 192, 336, 256, 256, 1) == 1 and pays(1, 192, 336, 256, 256, 1) == 1 and pays(1536, 14, 14, 256, 256, 0) == 1
-    assert pays(48, 24, 42, 512, 512, 1) == 0 and pays(48, 192, 336, 64, 64, 1) == 0
+    assert pays(48, 24, 42, 512, 512, 1) == 0 and pays(48, 192, 336, 64, 64, 1) == 1 and pays(48, 33, 33, 64, 64, 1) == 0     # 33 x 33 outputs in 3 x 3 tiles of 16 x 16
     assert lib.seam_f16pc_weight_halves(256, 256) == 256 * 256 * 9
 
 

@@ -190,6 +190,8 @@ def _f16pc_ref(x, wt, b, pc, pad, relu, bn):
     (37, 256, 14, 14, 256, 1, True, False), (23, 256, 8, 8, 1024, 0, True, False), (9, 256, 12, 12, 256, 0, False, True),
     (11, 128, 10, 10, 128, 0, True, False), (5, 128, 14, 14, 128, 0, True, False), (4, 256, 16, 16, 128, 0, True, True),
     (7, 128, 6, 6, 128, 1, True, False),
+    # C = K = 64 (conv3x3_f16pc64: one chunk per tile, weights stationary in registers): ragged edges, both paddings, 1 .. many tiles per block
+    (2, 64, 27, 45, 64, 1, True, True), (1, 64, 40, 70, 64, 0, False, False), (3, 64, 9, 26, 64, 1, True, False), (5, 64, 96, 168, 64, 1, True, True),
 ])
 def test_conv3x3_f16pc_matches_fp32_on_fp16_operands(ops, case):
     """seam_conv3x3_f16pc (producer / consumer fp16 3x3) against the fp32 convolution of the same fp16-rounded operands -- the bound of
@@ -228,7 +230,8 @@ def test_conv3x3_f16pc_many_tiles_per_block_is_repeatable(ops):
     old = ops.F16PC, ops.F16PC_RULE
     try:
         ops.F16PC_RULE = False
-        for seed, (n, c, hh, ww, k, pad) in enumerate([(1536, 256, 12, 12, 256, 0), (1536, 256, 8, 8, 1024, 0), (24, 256, 96, 168, 256, 1)]):
+        for seed, (n, c, hh, ww, k, pad) in enumerate([(1536, 256, 12, 12, 256, 0), (1536, 256, 8, 8, 1024, 0), (24, 256, 96, 168, 256, 1),
+                                                       (24, 64, 192, 336, 64, 1), (7, 64, 50, 75, 64, 0)]):
             g = torch.Generator(device=d); g.manual_seed(40 + seed)
             x = torch.randn(n, hh, ww, c, device=d, generator=g).half()
             wt = torch.randn(k, c, 3, 3, device=d, generator=g) / (3 * math.sqrt(c))
@@ -274,6 +277,9 @@ def test_conv3x3_f16pc_refuses_a_residual_and_dispatch_rule(ops):
     assert lib.seam_conv3x3_f16pc_pays(1536, 14, 14, 256, 256, 0) == 1      # 144 slots of a 160-slot tile
     assert lib.seam_conv3x3_f16pc_pays(48, 24, 42, 512, 512, 1) == 0        # 42 columns in 64
     assert lib.seam_conv3x3_f16pc_pays(1, 192, 336, 256, 256, 1) == 1       # the batch size takes no part
+    assert lib.seam_conv3x3_f16pc_pays(240, 192, 336, 64, 64, 1) == 1       # layer1's 3x3 layers (conv3x3_f16pc64)
+    assert lib.seam_conv3x3_f16pc_supported(64, 14, 14, 64, 64, 1) == 0     # ... on large maps only
+    assert lib.seam_conv3x3_f16pc_supported(8, 64, 64, 64, 128, 1) == 0 and lib.seam_conv3x3_f16pc_supported(8, 64, 64, 128, 64, 1) == 0
 
 
 @pytest.mark.parametrize("hw", [(64, 96), (70, 100)])

@@ -322,6 +322,8 @@ def stress_f16pc(rng):
             h = w if rng.random() < 0.7 else rng.choice([3, 5, 6, 8, 10, 12, 14, 16, 18])
         pad = rng.randint(0, 1)
         c, k = rng.choice([128, 256, 384, 512]), rng.choice([128, 256, 384, 1024])
+        if w >= 26 and rng.random() < 0.3:
+            c = k = 64                      # conv3x3_f16pc64 (round 6): one chunk per tile, weights in registers, 16 x 16 tiles
         if h + 2 * pad < 3 or w + 2 * pad < 3:
             continue
         n = pick_n(rng, h * w * max(c, k), 4 << 20)
@@ -354,7 +356,7 @@ def stress_f16pc(rng):
             refs.append(("torch F.conv2d", torch_epilogue(F.conv2d(x.float().permute(0, 3, 1, 2), wt, None, 1, pad).permute(0, 2, 3, 1), scale, shift, None, relu)))
         check("f16pc", desc, outs[0], outs[1], refs, 2e-3)
     dummy = torch.zeros(1 << 16, device=dev)
-    for (c, k) in [(64, 128), (128, 64), (192, 128), (136, 128)]:
+    for (c, k) in [(64, 128), (128, 64), (192, 128), (136, 128), (64, 64)]:       # (64 -> 64 is served on large maps only)
         if lib.seam_conv3x3_f16pc(P(dummy), P(dummy), None, None, None, P(dummy), 2, 14, 14, c, k, 1, 1, st()) == 0:
             fails.append(("f16pc", f"c={c} k={k}", "unserved channel count was not refused"))
     if lib.seam_conv3x3_f16pc(P(dummy), P(dummy), None, None, P(dummy), P(dummy), 2, 14, 14, 128, 128, 1, 1, st()) == 0:
