@@ -393,6 +393,8 @@ def main():
                 raise SystemExit(f"bench.py: rank {rank}: the all-gathered product bank differs between ranks after the warm-up "
                                  f"steps -- refusing to time (check the shard ranges / the collective)")
             log("bank identical on all ranks (pre-timing check)")
+        trace_marker()                  # (outside the timed region: the barrier + synchronize below come after it)
+        sync_all()
         log("timing")
         state["timed"] = multi and not args.graph
         t0 = time.perf_counter()
@@ -401,6 +403,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
         state["timed"] = False
+        trace_marker()
     if args.graph:
         last = graph_out
     per_rank_ms = None
@@ -701,6 +704,18 @@ def roofline_leg(step, dtype):
             "issued_tflop_per_step": round(sum(v[1] * mfma_issue_ratio(k)[0] for k, v in per.items()) / 1e12, 4),
             "other_variants": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[2], 3), "algorithmic_TFLOP/s": rate(v)}
                                for k, v in per.items() if k != dom}}
+
+
+def trace_marker():
+    """One launch of a kernel nothing else in the run uses (ATen's ``spin_kernel``, ~1 us) right before and right after the timed
+    region: ``tools/kernel_trace_steps.py`` cuts rocprofv3's kernel trace at the two launches, so the per-kernel averages committed
+    under ``profiles/`` are those of the K timed steps -- not diluted by the bank pass (same kernels on 256x256 shop images), the
+    warm-up or the instrumented legs behind the timed region."""
+    import torch
+    try:
+        torch.cuda._sleep(1)
+    except AttributeError:  # a torch build without the private helper: the trace is then summarised whole
+        pass
 
 
 def csrc_digest():

@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from seam_match_rcnn_amd import ops, _native
 DEFAULT = ["48,192,336,256,256,1", "1536,14,14,256,256,1", "48,96,168,256,256,1", "48,48,84,256,256,1", "1536,8,8,256,1024,0",
-           "48,96,168,128,128,1", "1536,12,12,256,256,0", "1536,10,10,256,256,0", "1536,14,14,256,256,0", "48,24,42,512,512,1"]
+           "48,96,168,128,128,1", "1536,12,12,256,256,0", "1536,10,10,256,256,0", "1536,14,14,256,256,0", "48,24,42,512,512,1",
+           "48,192,336,64,64,1"]
 shapes = [a for a in sys.argv[1:] if not a.startswith("--")] or DEFAULT
 dev = torch.device("cuda:0")
 lib = _native.lib()

@@ -13,7 +13,14 @@ python3 $R/bench.py > $O/${TAG}_bench.json 2>$O/${TAG}_bench.err
 rm -rf /tmp/prof_$TAG
 # kernel stats of the 8-clip steps only: --no-extras keeps the one-clip / full-forward legs (same kernels, other sizes) out of the averages
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o b -- python3 $R/bench.py --no-cpu-baseline --no-extras --single-stream > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
-cp /tmp/prof_$TAG/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null || cp /tmp/prof_$TAG/*/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv
+cp /tmp/prof_$TAG/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats_whole_run.csv 2>/dev/null || cp /tmp/prof_$TAG/*/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats_whole_run.csv
+# the TIMED STEPS only (bench.py brackets them with two spin_kernel launches): the whole-run file above also counts the bank pass
+# (the same kernels on 256x256 shop images), the warm-up and the instrumented roofline / parity legs
+python3 $R/tools/kernel_trace_steps.py $(ls /tmp/prof_$TAG/b_kernel_trace.csv /tmp/prof_$TAG/*/b_kernel_trace.csv 2>/dev/null | head -1) > $O/${TAG}_bench_kernel_stats.csv 2> $O/${TAG}_bench_kernel_stats_region.txt
+# the same for the config-5 (fp16) step
+rm -rf /tmp/prof5_$TAG
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5_$TAG -o b -- python3 $R/bench.py --dtype f16 --workload c5 --no-cpu-baseline --no-extras --steps 5 --warmup 1 > /dev/null 2>&1
+python3 $R/tools/kernel_trace_steps.py $(ls /tmp/prof5_$TAG/b_kernel_trace.csv /tmp/prof5_$TAG/*/b_kernel_trace.csv 2>/dev/null | head -1) > $O/${TAG}_c5_kernel_stats.csv 2> $O/${TAG}_c5_kernel_stats_region.txt
 python3 $R/bench.py --workload c3 --no-roofline --cpu-runs 1 > $O/${TAG}_bench_c3.json 2>/dev/null
 python3 $R/bench.py --workload c4 --no-roofline --no-cpu-baseline > $O/${TAG}_bench_c4.json 2>/dev/null
 python3 $R/bench.py --dtype f16 --no-cpu-baseline > $O/${TAG}_bench_f16.json 2>/dev/null
