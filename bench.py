@@ -712,6 +712,8 @@ def trace_marker():
     under ``profiles/`` are those of the K timed steps -- not diluted by the bank pass (same kernels on 256x256 shop images), the
     warm-up or the instrumented legs behind the timed region."""
     import torch
+    if not torch.cuda.is_available():       # the CPU flow of tests/test_bench_launch.py
+        return
     try:
         torch.cuda._sleep(1)
     except AttributeError:  # a torch build without the private helper: the trace is then summarised whole
