@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -86,6 +87,24 @@ __global__ void preprocess_s2d_kernel(const float* __restrict__ img, T* __restri
     float o[12];
     const float mean[3] = {0.485f, 0.456f, 0.406f};
     const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    // no resize, even row length, 8-byte aligned planes (the 1080p / 800^2 frames of the configs): the two pixels of a cell row are ONE
+    // 8-byte load per colour plane -- half the load instructions of the general form below, the same arithmetic on the same values
+    const bool pair = out_h == in_h && out_w == in_w && !(in_w & 1) && !(img_stride & 1) && !((size_t)img & 7);
+    if (pair) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = 2 * Y + r;
+            f32x2 v2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+            if (inside && y < out_h && 2 * X < out_w) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v2[c] = *reinterpret_cast<const f32x2*>(img + ((size_t)c * in_h + y) * in_w + 2 * X);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { v2[c][0] = (v2[c][0] - mean[c]) / stdv[c]; v2[c][1] = (v2[c][1] - mean[c]) / stdv[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { o[(2 * r) * 3 + c] = v2[c][0]; o[(2 * r + 1) * 3 + c] = v2[c][1]; }
+        }
+    } else
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const int y = 2 * Y + (d >> 1), x = 2 * X + (d & 1);
@@ -203,6 +222,43 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N
     }
 }
 
+// 3 x 3 / stride 2 / pad 1 (ResNet's pool after the stem -- the one large max-pool of the path): one thread = one output pixel x 16
+// bytes of channels; window coordinates CLAMPED into the map instead of tested (a clamped tap repeats a tap of the window: the
+// maximum is the same), 32-bit index arithmetic, nine independent 16-byte loads.  Same values as maxpool_kernel.
+template <typename T>
+__global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int Ho, int Wo, unsigned m_cv, unsigned m_Wo) {
+    typedef typename Vec16<T>::type V;
+    constexpr int E = Vec16<T>::N;
+    const int cv = C / E;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;           // (ho, wo, c) of image blockIdx.y
+    if (i >= (unsigned)(Ho * Wo * cv)) return;
+    const unsigned pix = cv == 1 ? i : __umulhi(i, m_cv);
+    const int c = (int)(i - pix * cv);
+    const int ho = (int)(Wo == 1 ? pix : __umulhi(pix, m_Wo));
+    const int wo = (int)pix - ho * Wo;
+    const T* xi = x + (size_t)blockIdx.y * H * W * C + c * E;
+    int hs[3], ws[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        hs[a] = min(max(2 * ho - 1 + a, 0), H - 1);
+        ws[a] = min(max(2 * wo - 1 + a, 0), W - 1);
+    }
+    V v[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) v[a * 3 + b] = *reinterpret_cast<const V*>(xi + (size_t)(hs[a] * W + ws[b]) * C);
+    V o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float m = (float)v[0][e];
+#pragma unroll
+        for (int t = 1; t < 9; ++t) m = fmaxf(m, (float)v[t][e]);
+        o[e] = (T)m;
+    }
+    *reinterpret_cast<V*>(y + ((size_t)blockIdx.y * Ho * Wo * cv + i) * E) = o;
+}
+
 template <typename T>
 __global__ void upsample_add_kernel(T* __restrict__ lat, const T* __restrict__ top, int N, int H, int W,
                                     int Ht, int Wt, int C) {
@@ -263,6 +319,43 @@ __global__ void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int K
     }
 }
 
+// the same sums in the same order (l = 0 .. L - 1 in fp32, one division), 16 bytes of channels per thread: the scalar form above
+// moves 2-4 bytes per lane and load (the 6 x 6 x 1024 trunk outputs of a config-5 step: 1.9 TB/s)
+template <typename T>
+__global__ void avgpool_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int K, int L, int C) {
+    typedef typename Vec16<T>::type V;
+    constexpr int E = Vec16<T>::N;
+    const int cv = C / E;
+    const size_t total = (size_t)K * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        const size_t k = i / cv;
+        const T* p = x + k * L * C + c * E;
+        float s[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] = 0.f;
+        int l = 0;
+        for (; l + 4 <= L; l += 4) {
+            V v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(p + (size_t)(l + u) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[e] += (float)v[u][e];
+        }
+        for (; l < L; ++l) {
+            const V v = *reinterpret_cast<const V*>(p + (size_t)l * C);
+#pragma unroll
+            for (int e = 0; e < E; ++e) s[e] += (float)v[e];
+        }
+        V o;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = (T)(s[e] / (float)L);
+        *reinterpret_cast<V*>(y + i * E) = o;
+    }
+}
+
 inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
     size_t g = (total + block - 1) / block;
     if (g > (size_t)cap) g = cap;
@@ -285,6 +378,14 @@ int maxpool(const void* x, void* y, int N, int H, int W, int C, int k, int strid
     if (C % Vec16<T>::N) return (int)hipErrorInvalidValue;
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const size_t total = (size_t)N * Ho * Wo * (C / Vec16<T>::N);
+    const size_t per_img = (size_t)Ho * Wo * (C / Vec16<T>::N);
+    if (k == 3 && stride == 2 && pad == 1 && H >= 2 && W >= 2 && N <= 65535 && per_img < (1u << 31) && (size_t)H * W * C < (1u << 31)) {
+        const unsigned cv = (unsigned)(C / Vec16<T>::N);
+        auto magic = [](unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
+        hipLaunchKernelGGL(maxpool3s2_kernel<T>, dim3((unsigned)((per_img + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)x, (T*)y, H, W, C, Ho, Wo, magic(cv), magic((unsigned)Wo));
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(maxpool_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, N,
                        H, W, C, Ho, Wo, k, stride, pad);
     return (int)hipGetLastError();
@@ -308,6 +409,11 @@ int transpose(const void* x, void* y, int B, int rows, int cols, void* stream) {
 
 template <typename T>
 int avgpool(const void* x, void* y, int K, int L, int C, void* stream) {
+    if (C % Vec16<T>::N == 0 && !((size_t)x & 15) && !((size_t)y & 15)) {
+        hipLaunchKernelGGL(avgpool_vec_kernel<T>, dim3(grid_for((size_t)K * (C / Vec16<T>::N), 256, 256 * 64)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)x, (T*)y, K, L, C);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(avgpool_kernel<T>, dim3(grid_for((size_t)K * C)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
                        (T*)y, K, L, C);
     return (int)hipGetLastError();

@@ -57,7 +57,7 @@ constexpr int PBUF = 56 * 1024;             // bytes per patch buffer (its last 
 // row pitch is padded to 9 Wo (mod 16), and the image pitch to 9 Ho Wo: the slot number of output o is 9 o (mod 16) again.
 // (Unpadded, the lane groups of the 8 x 8 ... 16 x 16 maps met 1.9 ... 3.0 pixels per bank group: the LDS, serving four consumer
 // waves one fragment per MFMA, was the bound of those layers -- tools/experiments/f16pc_banks.py.)
-constexpr int f16_rowp(int pwi) { return pwi == 34 ? 34 * 9 : 9 * (pwi - 2) + 32; }
+constexpr int f16_rowp(int pwi) { return pwi == 34 ? 34 * 9 : pwi == 18 ? 18 * 9 : 9 * (pwi - 2) + 32; }
 constexpr int NP = NPIXMAX * 8 / 256;       // 16-byte pieces per producer thread and chunk: 11
 constexpr int EX = PBUF;                    // LDS map: patch[2]; the finished fp16 tile (256 pixels x 256 bytes) overlays patch 1 and beyond;
 constexpr int SS = EX + 65536;              // then the tile's scale[128] | shift[128] fp32 row
@@ -68,7 +68,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS map");
 // 32-pixel groups of a block's tile as a function of the patch width: 8 (256 output slots) for the large maps; for the whole-map
 // form as many as the maps that fit need -- 16 x 16 inputs -> 14 x 14 outputs: 196 slots in 7 groups (8 would idle 23 % of every
 // MFMA); 14 -> 12 x 12: 144 in 5; 12 -> 10 x 10: two maps, 200 in 7; 10 -> 8 x 8: three maps, 192 in 6; 8 -> 6 x 6: five maps, 180 in 6
-constexpr int f16_nm(int pwi) { return pwi == 34 ? 8 : pwi == 16 ? 7 : pwi == 14 ? 5 : pwi == 12 ? 7 : 6; }
+constexpr int f16_nm(int pwi) { return pwi == 34 || pwi == 18 ? 8 : pwi == 16 ? 7 : pwi == 14 ? 5 : pwi == 12 ? 7 : 6; }
 // B fragments in flight per consumer wave (a divisor of the 36 steps of a chunk: the ring's phase repeats every chunk); the short
 // tiles look further ahead in steps -- the same distance in cycles
 constexpr int f16_rb(int nm) { return nm <= 6 ? 18 : 12; }
@@ -93,7 +93,7 @@ struct F16Args {
     void* y;               // [N, Ho, Wo, K] fp16
     int N, H, W, C, K, pad, relu;
     int Ho, Wo;
-    int mode;              // 0: 8 x 32 output patches of one image; 1: G whole images per block (Ho * Wo * G <= 256)
+    int mode;              // 0: 8 x 32 output patches of one image; 2: 16 x 16 output patches; 1: G whole images per block (Ho * Wo * G <= 256)
     int G;
     int PWi, PHi;          // input patch columns / rows per image slot
     int npix;              // patch pixels per block (<= NPIXMAX)
@@ -109,17 +109,19 @@ __device__ __forceinline__ int fdivu(int a, int d, unsigned m) { return d == 1 ?
 
 // wave-uniform geometry of one tile
 struct F16Geo { int tn, img0, n_here, y0, x0; };
+// MODE 0: 8 x 32 output patches of one image; 2: 16 x 16 output patches (round 6: maps that 32-column patches tile badly -- 192 x 336
+// leaves 4.5 % of every 8 x 32 launch on columns that do not exist, 96 x 168 12.5 %); 1: G whole small images per block
 template <int MODE>
 __device__ __forceinline__ F16Geo f16_geo(const F16Args& p, const int tile) {
     F16Geo g;
     const int tm = fdivu(tile, p.tiles_n, p.m_tiles_n);
     g.tn = tile - tm * p.tiles_n;
-    if (MODE == 0) {
+    if (MODE != 1) {
         const int img = fdivu(tm, p.per_img, p.m_per_img);
         const int rb = tm - img * p.per_img;
         const int byi = fdivu(rb, p.bx, p.m_bx);
         g.img0 = img; g.n_here = 1;
-        g.y0 = byi * 8; g.x0 = (rb - byi * p.bx) * 32;
+        g.y0 = byi * (MODE == 0 ? 8 : 16); g.x0 = (rb - byi * p.bx) * (MODE == 0 ? 32 : 16);
     } else {
         g.img0 = tm * p.G; g.n_here = min(p.G, p.N - g.img0);
         g.y0 = 0; g.x0 = 0;
@@ -130,6 +132,7 @@ __device__ __forceinline__ F16Geo f16_geo(const F16Args& p, const int tile) {
 template <int MODE>
 __device__ __forceinline__ void f16_slot(const F16Args& p, const int o, int& g, int& oy, int& ox) {
     if (MODE == 0) { g = 0; oy = o >> 5; ox = o & 31; return; }
+    if (MODE == 2) { g = 0; oy = o >> 4; ox = o & 15; return; }
     const int HoWo = p.Ho * p.Wo;
     g = fdivu(o, HoWo, p.m_HoWo);
     const int rm = o - g * HoWo;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < 4;
     constexpr int NM = f16_nm(PWI), RB = f16_rb(NM), ROWP = f16_rowp(PWI);
-    constexpr int MODE = PWI == 34 ? 0 : 1;          // large maps in 8 x 32 patches | G whole small maps per block
+    constexpr int MODE = PWI == 34 ? 0 : PWI == 18 ? 2 : 1;      // large maps in 8 x 32 or 16 x 16 patches | G whole small maps per block
     const int n = p.nchunks;
 
     // ---- the block's tiles: XCD x (= blockIdx & 7) owns a contiguous range of the launch's tiles; its blocks walk it interleaved ----
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 const int pix = (ptid >> 3) + 32 * r;
-                const int g = MODE ? fdivu(pix, slotpix, p.m_slotpix) : 0;
+                const int g = MODE == 1 ? fdivu(pix, slotpix, p.m_slotpix) : 0;
                 const int rm = pix - g * slotpix;
                 const int iy = fdivu(rm, p.PWi, p.m_PWi);
                 const int ix = rm - iy * p.PWi;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 const int pix = (ptid >> 3) + 32 * r;
-                const int g = MODE ? fdivu(pix, slotpix, p.m_slotpix) : 0;
+                const int g = MODE == 1 ? fdivu(pix, slotpix, p.m_slotpix) : 0;
                 const int rm = pix - g * slotpix;
                 const int iy = fdivu(rm, p.PWi, p.m_PWi);
                 const int ix = rm - iy * p.PWi;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
                         int g, oy, ox;
                         f16_slot<MODE>(p, o, g, oy, ox);
                         const int gy = qe.y0 + oy, gx = qe.x0 + ox;
-                        const bool ok = g < qe.n_here && gy < p.Ho && gx < p.Wo && (MODE == 0 || o < p.G * p.Ho * p.Wo);
+                        const bool ok = g < qe.n_here && gy < p.Ho && gx < p.Wo && (MODE != 1 || o < p.G * p.Ho * p.Wo);
                         const unsigned off = ok ? (unsigned)(__mul24(__mul24(__mul24(g, p.Ho) + gy, p.Wo) + gx, p.K) + ncol) * 2u : kOob;
                         // rows with bit 4 set keep their two 8-byte halves swapped (the consumers' conflict-free write pattern)
                         const u32x4 w = (it & 1) ? u32x4{v[i][2], v[i][3], v[i][0], v[i][1]} : v[i];
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16pc(const F16Args p) {
         for (int m = 0; m < NM; ++m) {
             int g, oy, ox;
             f16_slot<MODE>(p, 32 * m + (lane & 31), g, oy, ox);
-            if (MODE && 32 * m + (lane & 31) >= p.G * p.Ho * p.Wo) { g = 0; oy = 0; ox = 0; }      // idle slots read pixel 0 (never stored)
+            if (MODE == 1 && 32 * m + (lane & 31) >= p.G * p.Ho * p.Wo) { g = 0; oy = 0; ox = 0; }      // idle slots read pixel 0 (never stored)
             ab[m] = (LDSQ char*)smem + (__mul24(g, p.imgp) + oy * ROWP + ox * 9) * 16 + (lane >> 5) * 16;
         }
         const int wchunk_bytes = 9 * 4 * 1024;                      // one chunk of one n-tile: 9 taps x 4 k-steps x 1 KiB
@@ -730,6 +733,12 @@ int f16pc_plan(F16Args& a, int N, int H, int W, int C, int K, int pad) {
         a.mode = 0; a.G = 1;
         a.PWi = 34; a.PHi = 10; a.npix = 340; a.imgp = 10 * f16_rowp(34);
         a.bx = (a.Wo + 31) / 32; a.by = (a.Ho + 7) / 8;
+        {   // 16 x 16 patches where they leave fewer empty slots (the same sums in the same order: the results do not depend on it)
+            const int bx2 = (a.Wo + 15) / 16, by2 = (a.Ho + 15) / 16;
+            if (!c64 && bx2 * by2 < a.bx * a.by && seam_opt::get(seam_opt::F16PC_TILE16)) {
+                a.mode = 2; a.PWi = 18; a.PHi = 18; a.npix = 324; a.imgp = 18 * f16_rowp(18); a.bx = bx2; a.by = by2;
+            }
+        }
         if (c64) { a.PWi = 18; a.PHi = 18; a.npix = 324; a.imgp = 18 * ROWP64; a.bx = (a.Wo + 15) / 16; a.by = (a.Ho + 15) / 16; }
         a.per_img = a.bx * a.by;
         a.tiles_m = N * a.per_img;
@@ -809,8 +818,8 @@ int seam_conv3x3_f16pc_supported(int N, int H, int W, int C, int K, int pad) {
 int seam_conv3x3_f16pc_pays(int N, int H, int W, int C, int K, int pad) {
     F16Args a;
     if (f16pc_plan(a, N, H, W, C, K, pad)) return 0;
-    const double slots = a.mode == 0 ? (double)a.bx * a.by * 256.0 : 32.0 * f16_nm(a.PWi);
-    const double used = a.mode == 0 ? (double)a.Ho * a.Wo : (double)a.G * a.Ho * a.Wo;
+    const double slots = a.mode != 1 ? (double)a.bx * a.by * 256.0 : 32.0 * f16_nm(a.PWi);
+    const double used = a.mode != 1 ? (double)a.Ho * a.Wo : (double)a.G * a.Ho * a.Wo;
     return used >= 0.75 * slots ? 1 : 0;
 }
 
@@ -835,6 +844,7 @@ int seam_conv3x3_f16pc(const void* x, const void* w_packed, const float* scale, 
     if (a.K == 64) return f16pc64_launch(a, st);
     switch (a.PWi) {
         case 34: return f16pc_launch<34>(a, st);
+        case 18: return f16pc_launch<18>(a, st);
         case 16: return f16pc_launch<16>(a, st);
         case 14: return f16pc_launch<14>(a, st);
         case 12: return f16pc_launch<12>(a, st);

@@ -15,8 +15,8 @@ enum Id {
     W24_PERSIST,       // 1 (default): conv3x3_wino24pc as one persistent block per CU; 0: one tile per block
     W24_NSPLIT,        // 0 (default): n-tile split over XCD groups chosen by the launcher (1 today); > 0 forces it
     W24_DYNLDS,        // extra dynamic LDS of conv3x3_wino24<NT> (occupancy experiments), default 0
-    W24_WLDS,          // 1 (default): conv3x3_wino24pc takes its weight fragments through LDS (staged by the producer waves); 0: the
-                       //   consumers' own register ring (the round-5 form)
+    F16PC_TILE16,      // 1 (default): conv3x3_f16pc tiles a large map in 16 x 16 patches where those leave fewer empty slots than
+                       //   8 x 32 ones; 0: always 8 x 32 (the round-5 form; same results)
     CONV_TILE,         // 0 (default): the implicit GEMM picks its block tile; BM * 1000 + BN forces one
     F16_VEC_EPILOGUE,  // default 1
     EPI_PRIO,          // default 1
@@ -31,7 +31,7 @@ enum Id {
 
 struct Entry { const char* name; int dflt; };
 constexpr Entry kTable[COUNT] = {
-    {"SEAM_W24_PC", 1}, {"SEAM_W24_NT", 0}, {"SEAM_W24_PERSIST", 1}, {"SEAM_W24_NSPLIT", 0}, {"SEAM_W24_DYNLDS", 0}, {"SEAM_W24_WLDS", 1},
+    {"SEAM_W24_PC", 1}, {"SEAM_W24_NT", 0}, {"SEAM_W24_PERSIST", 1}, {"SEAM_W24_NSPLIT", 0}, {"SEAM_W24_DYNLDS", 0}, {"SEAM_F16PC_TILE16", 1},
     {"SEAM_CONV_TILE", 0}, {"SEAM_F16_VEC_EPILOGUE", 1}, {"SEAM_EPI_PRIO", 1}, {"SEAM_CONV_SLOTS", 512}, {"SEAM_CONV_DYNLDS", 0},
     {"SEAM_PW_BLOCKS", 256}, {"SEAM_WINO_MT", 0}, {"SEAM_WINO_NSPLIT", 0}, {"SEAM_ROIALIGN_LDS", 2},
 };

@@ -139,6 +139,13 @@ def test_maxpool_upsample_transpose_avgpool(ops):
     x = rnd(30, (2, 64, 31, 37))
     assert_close(ops.maxpool2d(nhwc(x).to(d), 3, 2, 1).permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2, 1), rtol=0, atol_scale=0)
     assert_close(ops.maxpool2d(nhwc(x).to(d), 1, 2, 0).permute(0, 3, 1, 2), F.max_pool2d(x, 1, 2, 0), rtol=0, atol_scale=0)
+    # the 3x3 / stride-2 / pad-1 form has its own kernel (clamped window coordinates): even, odd and tiny maps, a channel count of one
+    # 16-byte vector, an all-negative map (the padding must never win)
+    for i, shp in enumerate([(3, 64, 40, 56), (1, 8, 2, 2), (2, 8, 3, 5), (1, 128, 7, 64), (2, 16, 2, 9)]):
+        xs = rnd(300 + i, shp) - (5.0 if i == 1 else 0.0)
+        assert torch.equal(ops.maxpool2d(nhwc(xs).to(d), 3, 2, 1).permute(0, 3, 1, 2).cpu(), F.max_pool2d(xs, 3, 2, 1)), shp
+        xh = xs.half()
+        assert torch.equal(ops.maxpool2d(nhwc(xh).to(d), 3, 2, 1).permute(0, 3, 1, 2).float().cpu(), F.max_pool2d(xh.float(), 3, 2, 1)), shp
     lat, top = rnd(31, (2, 32, 26, 34)), rnd(32, (2, 32, 13, 17))
     ref = lat + F.interpolate(top, size=lat.shape[-2:], mode="nearest")
     got = ops.upsample_add_(nhwc(lat).to(d), nhwc(top).to(d))
