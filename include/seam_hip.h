@@ -133,6 +133,19 @@ int seam_conv1x1_sw_f32(const float* x, const float* x2, const float* w, const f
                         int M, int C1, int C2, int K, int relu, int res_mode, int Ho, int Wo, int rH, int rW,
                         seam_stream_t stream);
 
+/* conv1x1_f16pc (csrc/seam_pwhpc.hip, round 6): the fp16 1x1 / stride-1 layers with a LONG reduction (C >= 512, a multiple of 256; K a
+ * multiple of 128) as a producer / consumer block -- the fp16 twin of seam_conv1x1_pc_f32.  Replaces, for those shapes, the reference's
+ * `torch.nn.Conv2d(C, K, 1)` + FrozenBatchNorm2d + ReLU of torchvision's Bottleneck.conv1 (reached from
+ * /root/reference/models/video_matchrcnn.py:57-66 through `resnet_fpn_backbone`) under autocast-free fp16 operands.
+ *   _supported: 1 when the shape is served;  _weight_halves: fp16 elements of the packed weights;
+ *   seam_pack_conv1x1_weight_f16pc: w [K, C] fp32 row-major -> fragment order;
+ *   seam_conv1x1_f16pc: y[M, K] = act(scale * (x[M, C] . w^T) + shift), fp16 in / out, fp32 accumulation; `residual` must be NULL. */
+int seam_conv1x1_f16pc_supported(long long M, int C, int K);
+long long seam_conv1x1_f16pc_weight_halves(int K, int C);
+int seam_pack_conv1x1_weight_f16pc(const float* w, void* w_packed, int K, int C, seam_stream_t stream);
+int seam_conv1x1_f16pc(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
+                       long long M, int C, int K, int relu, seam_stream_t stream);
+
 /* fp16 twin of seam_conv1x1_sw_f32 (csrc/seam_pwh.hip, round 6): the config-5 path's 1x1 layers [TV Bottleneck conv1 / conv3 /
  * stride-1 projection shortcut, FeaturePyramidNetwork.inner_blocks; behind models/video_matchrcnn.py:337] as a STREAMING kernel --
  * weights stationary in LDS, independent waves, 16-byte NHWC pieces in and out -- with the contract of seam_conv2d_f16 /

@@ -58,6 +58,10 @@ SIGNATURES = {
     "seam_conv1x1_sw_config": (_i, [_i, _i, _i, _i]),
     "seam_conv1x1_sw_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_conv1x1_swh_config": (_i, [C.c_longlong, _i, _i, _i]),
+    "seam_conv1x1_f16pc_supported": (_i, [C.c_longlong, _i, _i]),
+    "seam_conv1x1_f16pc_weight_halves": (C.c_longlong, [_i, _i]),
+    "seam_pack_conv1x1_weight_f16pc": (_i, [_p, _p, _i, _i, _p]),
+    "seam_conv1x1_f16pc": (_i, [_p, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i, _p]),
     "seam_conv1x1_swh_f16": (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "seam_stem_s2d_swh_f16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "seam_conv2d_dual_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

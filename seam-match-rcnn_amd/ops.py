@@ -65,6 +65,7 @@ class PackedConv:
     wq: Optional[torch.Tensor] = None   # fp32 1x1 / stride-1 layers with C >= 256 (a multiple of 128), K % 128 == 0: fragment-order weights of seam_conv1x1_pc_f32
     wh: Optional[torch.Tensor] = None   # fp16 stride-1 3x3 layers (C, K multiples of 128, or C = K = 64): fragment-order weights of seam_conv3x3_f16pc
     wsh: Optional[torch.Tensor] = None  # fp16 1x1 / stride-1 layers (C multiple of 64, <= 512): row-major fp16 [K, C] weights of seam_conv1x1_swh_f16
+    wph: Optional[torch.Tensor] = None  # fp16 1x1 / stride-1 layers with C >= 512 (a multiple of 256), K a multiple of 128: fragment-order weights of seam_conv1x1_f16pc
 
 
 BX3 = "bf16x3"      # fp32 activations, split-bf16 operands (3 bf16 MFMAs per product, fp32 accumulate)
@@ -85,6 +86,8 @@ PWPC = _os.environ.get("SEAM_PWPC", "1") != "0"
 # fp16 path: the 1x1 / stride-1 layers through the streaming weights-stationary kernel (csrc/seam_pwh.hip, round 6); SEAM_PWH=0 keeps
 # them on the implicit GEMM.  Maps of >= SW_MIN_HW pixels only -- a function of the map, like the fp32 rule.
 SWH = _os.environ.get("SEAM_PWH", "1") != "0"
+PWHPC = _os.environ.get("SEAM_PWHPC", "1") != "0"       # conv1x1_f16pc: the long-reduction fp16 1x1 layers (csrc/seam_pwhpc.hip)
+PWHPC_MIN_C = int(_os.environ.get("SEAM_PWHPC_MIN_C", "1024"))  # reductions from this length on take it (C = 512 stays on conv1x1_swh: 1.04-1.2x alone, nothing in the step)
 F16PC_RULE = True      # dispatch by seam_conv3x3_f16pc_pays (False: every supported shape -- tests, tools/f16pc_ab.py)
 
 
@@ -265,7 +268,13 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn=None
             and lib.seam_conv1x1_swh_config(1 << 20, cs, 0, K)):
         wm = weight.permute(2, 3, 1, 0).reshape(K, cin) if transposed2x2 else weight.reshape(K, cin)
         wsh = wm.to(F16).contiguous()
-    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw, wq, wh, wsh)
+    wph = None
+    if (PWHPC and dtype == F16 and mode == 0 and not is_linear and R == 1 and S == 1 and stride == 1 and pad == 0 and cs == cin
+            and lib.seam_conv1x1_f16pc_supported(1 << 20, cs, K)):
+        wph = torch.empty((int(lib.seam_conv1x1_f16pc_weight_halves(K, cs)),), dtype=F16, device=weight.device)
+        _native.check(lib.seam_pack_conv1x1_weight_f16pc(_ptr(weight.reshape(K, cin).to(F32).contiguous()), _ptr(wph), K, cs, _stream()),
+                      "seam_pack_conv1x1_weight_f16pc")
+    return PackedConv(wp, scale, shift, K, cs, R, S, stride, pad, cin, dtype, u, u24, wn, ws, shift_sw, wq, wh, wsh, wph)
 
 
 def pack_conv_dgrad(weight: torch.Tensor, pad_fwd: int = 0, wino: bool = True) -> PackedConv:
@@ -453,9 +462,15 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
             and lib.seam_conv1x1_pc_supported(n * h * w, c, pc.K) == 1)
     f16pc = (pc.dtype == F16 and pc.wh is not None and F16PC and residual is None and out_hw is None and not out_f32 and relu in (0, 1, False, True)
              and (lib.seam_conv3x3_f16pc_pays if F16PC_RULE else lib.seam_conv3x3_f16pc_supported)(n, h, w, c, pc.K, pc.pad) == 1)
-    swh = (pc.dtype == F16 and pc.wsh is not None and SWH and out_hw is None and not out_f32 and h * w >= SW_MIN_HW
+    pwhpc = (pc.dtype == F16 and pc.wph is not None and PWHPC and residual is None and out_hw is None and not out_f32
+             and relu in (0, 1, False, True) and c >= PWHPC_MIN_C and h * w >= SW_MIN_HW
+             and lib.seam_conv1x1_f16pc_supported(n * h * w, c, pc.K) == 1)
+    swh = (not pwhpc and pc.dtype == F16 and pc.wsh is not None and SWH and out_hw is None and not out_f32 and h * w >= SW_MIN_HW
            and relu in (0, 1, False, True))
-    if swh:
+    if pwhpc:
+        _native.check(lib.seam_conv1x1_f16pc(_ptr(x), _ptr(pc.wph), _ptr(pc.scale), _ptr(pc.shift), None, _ptr(y), n * h * w, c, pc.K,
+                                             1 if relu else 0, _stream()), "seam_conv1x1_f16pc")
+    elif swh:
         _native.check(lib.seam_conv1x1_swh_f16(_ptr(x), None, _ptr(pc.wsh), _ptr(pc.scale), _ptr(pc.shift), _ptr(residual), _ptr(y),
                                                n * h * w, c, 0, pc.K, 1 if relu else 0, 1 if residual is not None else 0, 0, 0, 0, 0,
                                                _stream()), "seam_conv1x1_swh_f16")
@@ -495,7 +510,9 @@ def conv2d(x: torch.Tensor, pc: PackedConv, relu: bool = False, residual: Option
     if trace is not None:
         e1.record()
         tile = lib.seam_conv_tile_taps(2 if pc.dtype == BX3 else 1 if pc.dtype == F16 else 0, n * ho * wo, pc.K, pc.R * pc.S)
-        if swh:
+        if pwhpc:
+            variant = "conv1x1_f16pc"
+        elif swh:
             variant = _swh_variant(lib, n * h * w, c, pc.K)
         elif narrow:
             variant = "linear_narrow"

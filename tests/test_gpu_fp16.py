@@ -255,6 +255,69 @@ def test_conv3x3_f16pc_many_tiles_per_block_is_repeatable(ops):
         ops.F16PC, ops.F16PC_RULE = old
 
 
+@pytest.mark.parametrize("case", [
+    # n, C, H, W, K, relu, bn      M ragged against the 256-row tiles, 4 .. 16 chunks, 1 .. 4 n-tiles, one tile .. many tiles per block
+    (3, 512, 27, 45, 128, True, True), (2, 1024, 40, 70, 256, True, False), (1, 2048, 9, 26, 512, False, False),
+    (5, 768, 33, 31, 384, True, True), (240, 1024, 12, 21, 256, True, True), (1, 512, 14, 14, 2048, False, True),
+])
+def test_conv1x1_f16pc_matches_fp32_on_fp16_operands(ops, case):
+    """seam_conv1x1_f16pc (producer / consumer fp16 1x1 with a long reduction, round 6) against the fp32 product of the same fp16-rounded
+    operands and against conv_igemm<_Float16> / conv1x1_swh to accumulation-order rounding; twice onto a poisoned output, bit for bit."""
+    import seam_match_rcnn_amd._native as native
+    n, c, hh, ww, k, relu, bn = case
+    d = dev()
+    assert native.lib().seam_conv1x1_f16pc_supported(n * hh * ww, c, k) == 1
+    x = rnd(700, (n, c, hh, ww)).half().float()
+    wt = rnd(701, (k, c, 1, 1), "w") / math.sqrt(c)
+    if bn:
+        b = (torch.from_numpy(synth.uniform(synth.stream_id(702, "bw"), (k,), 0.5, 1.5)), rnd(703, (k,), "bb") * 0.1,
+             rnd(704, (k,), "rm") * 0.1, torch.from_numpy(synth.uniform(synth.stream_id(705, "rv"), (k,), 0.5, 1.5)))
+        pc = ops.pack_conv(wt.to(d), None, stride=1, pad=0, bn=tuple(t.to(d) for t in b), dtype=H)
+        sc = b[0] * (b[3] + 1e-5).rsqrt()
+        folded = pc.scale is None
+        w16 = ((wt * sc[:, None, None, None]) if folded else wt).half().float()
+        ref = F.conv2d(x, w16)
+        ref = (ref if folded else ref * sc[None, :, None, None]) + (b[1] - b[2] * sc)[None, :, None, None]
+    else:
+        bias = rnd(702, (k,), "b") * 0.1
+        pc = ops.pack_conv(wt.to(d), bias.to(d), stride=1, pad=0, dtype=H)
+        ref = F.conv2d(x, wt.half().float(), bias)
+    ref = F.relu(ref) if relu else ref
+    assert pc.wph is not None
+    xd = nhwc(x).half().to(d)
+    old = ops.PWHPC, ops.CONV_TRACE, ops.PWHPC_MIN_C
+    try:
+        ops.PWHPC = True
+        ops.PWHPC_MIN_C = 512
+        ops.CONV_TRACE = []
+        got = torch.full((n, hh, ww, k), 777.0, dtype=H, device=d)
+        ops.conv2d(xd, pc, relu, out=got)
+        assert [t[0] for t in ops.CONV_TRACE] == ["conv1x1_f16pc"]
+        ops.CONV_TRACE = None
+        again = torch.full((n, hh, ww, k), -333.0, dtype=H, device=d)
+        ops.conv2d(xd, pc, relu, out=again)
+        ops.PWHPC = False
+        other = ops.conv2d(xd, pc, relu)
+    finally:
+        ops.PWHPC, ops.CONV_TRACE, ops.PWHPC_MIN_C = old
+    assert torch.equal(got, again)
+    assert_close(got.float().permute(0, 3, 1, 2), ref, rtol=2e-3, atol_scale=1e-3)
+    scale = float(ref.abs().max())
+    assert float((got.float() - other.float()).abs().max()) <= 2e-3 * scale
+
+
+def test_conv1x1_f16pc_refuses_what_it_does_not_serve(ops):
+    import seam_match_rcnn_amd._native as native
+    lib = native.lib()
+    sup = lib.seam_conv1x1_f16pc_supported
+    assert sup(1000, 512, 128) == 1 and sup(1, 2048, 2048) == 1
+    assert sup(1000, 256, 128) == 0 and sup(1000, 640, 128) == 0 and sup(1000, 512, 64) == 0 and sup(0, 512, 128) == 0
+    d = dev()
+    z = torch.zeros(1 << 16, dtype=H, device=d)
+    assert lib.seam_conv1x1_f16pc(z.data_ptr(), z.data_ptr(), None, None, z.data_ptr(), z.data_ptr(), 64, 512, 128, 1, None) != 0     # residual
+    assert lib.seam_conv1x1_f16pc(z.data_ptr(), z.data_ptr(), None, None, None, z.data_ptr(), 64, 384, 128, 1, None) != 0             # C
+
+
 def test_conv3x3_f16pc_refuses_a_residual_and_dispatch_rule(ops):
     import seam_match_rcnn_amd._native as native
     lib = native.lib()

@@ -2,7 +2,7 @@
 
 ``conv3x3_wino24pc`` (persistent producer / consumer Winograd F(2x4,3x3), hand-counted ``vmcnt`` waits, a cross-tile software
 pipeline, cached per-region addresses, 24-bit multiplies guarded by launcher caps), ``conv1x1_pc``, ``conv3x3_f16pc``,
-``conv1x1_sw``, ``conv1x1_swh`` and the fp16 stem on the streaming kernel (round 6) each get >= 200 seeded random shapes: every launch goes onto a POISONED output, twice, and must be bit-identical;
+``conv1x1_sw``, ``conv1x1_swh``, ``conv1x1_f16pc`` and the fp16 stem on the streaming kernel (round 6) each get >= 200 seeded random shapes: every launch goes onto a POISONED output, twice, and must be bit-identical;
 results are compared with the implicit GEMM (``seam_conv2d_f32`` / ``_f16``) AND with a plain torch fp32 convolution of the same
 operands (tap-wise ``matmul`` form for every shape -- no per-shape MIOpen search -- and ``F.conv2d`` itself on a sample).
 Unserved channel counts must be REFUSED (non-zero return), not hang.  Shapes cover N in [1, 3000], H, W in [3, 210] including
@@ -425,6 +425,51 @@ def stress_sw(rng):
     say(f"SUMMARY conv1x1_sw cases {done} seconds {time.time() - t0:.1f}")
 
 
+# ------------------------------------------------------------------------------------------------ conv1x1_f16pc (fp16, long reductions)
+def stress_pwhpc(rng):
+    t0 = time.time()
+    done = exact = 0
+    while done < NCASE:
+        c = rng.choice([512, 768, 1024, 1536, 2048])
+        k = rng.choice([128, 256, 384, 512, 1024, 2048])
+        h, w = dim(rng, 1, 120), dim(rng, 1, 120)
+        n = pick_n(rng, h * w * max(c, k), 3 << 20)
+        m = n * h * w
+        if lib.seam_conv1x1_f16pc_supported(m, c, k) != 1:
+            continue
+        done += 1
+        g = gen(rng)
+        relu = rng.choice([0, 1])
+        desc = f"m={m} c={c} k={k} relu={relu}"
+        say("START conv1x1_f16pc", desc)
+        x = torch.randn(m, c, device=dev, generator=g).half()
+        wt = (torch.randn(k, c, device=dev, generator=g) / math.sqrt(c)).half().float()
+        scale, shift = epilogue_vectors(rng, k, g)
+        wp = torch.empty((int(lib.seam_conv1x1_f16pc_weight_halves(k, c)),), dtype=torch.float16, device=dev)
+        assert lib.seam_pack_conv1x1_weight_f16pc(P(wt), P(wp), k, c, st()) == 0
+        outs = []
+        for rep in range(2):
+            y = poisoned((m, k), torch.float16, rep)
+            rc = lib.seam_conv1x1_f16pc(P(x), P(wp), P(scale), P(shift), None, P(y), m, c, k, relu, st())
+            assert rc == 0, (desc, rc)
+            outs.append(y)
+        refs = [("torch fp32 matmul", torch_epilogue(x.float() @ wt.t(), scale, shift, None, relu))]
+        wi = torch.empty((lib.seam_conv_rows_padded(k), lib.seam_conv_kred_f16(c, 1, 1)), dtype=torch.float16, device=dev)
+        assert lib.seam_pack_conv_weight_f16(P(wt), P(wi), k, c, 1, 1, c, 0, st()) == 0
+        yi = poisoned((m, k), torch.float16, 0)
+        assert lib.seam_conv2d_f16(P(x), P(wi), P(scale), P(shift), None, P(yi), 1, 1, m, c, k, 1, 1, 1, 0, relu, 0, st()) == 0
+        refs.append(("implicit GEMM (fp16)", yi))
+        exact += int(torch.equal(outs[0], yi))
+        check("conv1x1_f16pc", desc, outs[0], outs[1], refs, 2e-3)
+    dummy = torch.zeros(1 << 16, dtype=torch.float16, device=dev)
+    for (c, k) in [(256, 128), (384, 256), (640, 128), (512, 64), (512, 192)]:
+        if lib.seam_conv1x1_f16pc(P(dummy), P(dummy), None, None, None, P(dummy), 64, c, k, 0, st()) == 0:
+            fails.append(("conv1x1_f16pc", f"c={c} k={k}", "unserved channel count was not refused"))
+    if lib.seam_conv1x1_f16pc(P(dummy), P(dummy), None, None, P(dummy), P(dummy), 64, 512, 128, 0, st()) == 0:
+        fails.append(("conv1x1_f16pc", "residual", "a residual operand was not refused"))
+    say(f"SUMMARY conv1x1_f16pc cases {done} bit-identical-to-implicit-GEMM {exact} seconds {time.time() - t0:.1f}")
+
+
 # ------------------------------------------------------------------------------------------------ conv1x1_swh (fp16)
 def stress_swh(rng):
     t0 = time.time()
@@ -520,7 +565,7 @@ def stress_stem(rng):
 
 
 for idx, (name, fn) in enumerate([("wino24pc", stress_wino24pc), ("conv1x1_pc", stress_pwpc), ("f16pc", stress_f16pc), ("conv1x1_sw", stress_sw),
-                                  ("conv1x1_swh", stress_swh), ("stem_swh", stress_stem)]):
+                                  ("conv1x1_swh", stress_swh), ("stem_swh", stress_stem), ("conv1x1_f16pc", stress_pwhpc)]):
     if len(sys.argv) > 3 and name not in sys.argv[3:]:
         continue
     before = len(fails)
@@ -588,7 +633,11 @@ def test_stress_stem_swh(sweep):
     _kernel_ok(sweep, "stem_swh")
 
 
+def test_stress_conv1x1_f16pc(sweep):
+    _kernel_ok(sweep, "conv1x1_f16pc")
+
+
 def test_stress_sweep_is_fast(sweep):
     """<= 90 s of sweep (VERDICT's bound), measured inside the child (process start-up and ``import torch`` excluded)."""
     secs = [float(ln.split()[-1]) for ln in sweep["out"].splitlines() if ln.startswith("SUMMARY")]
-    assert len(secs) == 6 and sum(secs) <= 90.0, secs
+    assert len(secs) == 7 and sum(secs) <= 90.0, secs
