@@ -56,6 +56,7 @@ bash $R/tools/w24pc_ab.sh $TAG > /dev/null 2>&1
 { python3 $R/tools/f16pc_ab.py --full; python3 $R/tools/f16pc_ab.py --relu-input 48,192,336,256,256,1; python3 $R/tools/f16pc_ab.py --zeros 48,192,336,256,256,1; } 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_f16pc_ab.txt
 bash $R/tools/pmc_f16pc.sh 48,192,336,256,256,1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES > $O/${TAG}_f16pc_pmc.txt 2>&1
 python3 $R/tools/pwh_ab.py 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_pwh_ab.txt
+python3 $R/tools/pwhpc_ab.py 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_pwhpc_ab.txt
 python3 $R/tools/wino_nsplit_ab.py 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_wino_nsplit_ab.txt
 python3 $R/tools/f44_noise_probe.py 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_f44_noise_probe.txt
 ls -la $O | grep $TAG
