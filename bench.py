@@ -65,7 +65,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the value_clips1 / full_forward_ms_per_clip legs")
@@ -82,11 +82,11 @@ def parse():
                          "per-kernel profiles (rocprofv3 --stats, the PMC passes) are taken with this flag; the roofline leg always "
                          "instruments a single-stream step)")
     ap.add_argument("--two-streams", action="store_true",
-                    help="fp16 path only (--dtype f16): run the body on two HIP streams like the fp32 path.  The fp16 default is ONE stream: "
-                         "its persistent one-block-per-CU kernels (conv3x3_f16pc, conv1x1_swh) partition a launch's tiles statically, and "
-                         "when the other stream's kernel holds part of the CUs at launch the late blocks serialise -- observed as a bimodal "
-                         "step (157-166 ms on six boxes, 215-220 ms twice, same code; the single-stream instrumented step of those two "
-                         "runs: 157 ms); two streams are worth 2 %% when they interleave well")
+                    help="fp16 path only (--dtype f16): run the body on two HIP streams like the fp32 path (1.5 %% faster; 91-106 GB of "
+                         "allocator pools instead of 48).  The fp16 default is ONE stream.  The 205-220 ms lines once seen with two streams "
+                         "were hipMalloc stalls INSIDE the timed region (side-stream tensors are record_stream-ed, an unpaced host ran the "
+                         "whole timed region ahead, the caching allocator grew step by step; 100+ ms per call on a box whose HBM had not been "
+                         "touched since boot) -- the timed loop now keeps the host two steps ahead at most (DESIGN 3.4)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the clip the CPU baseline times (default: all)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU runs after one warm-up; the minimum is reported")
     ap.add_argument("--graph", action="store_true",
@@ -381,10 +381,20 @@ def main():
     log("warmup")
     last = None
     with torch.no_grad():
+        # (the warm-up runs at the timed loop's queue depth -- not synchronised step by step -- so that the caching allocator meets the
+        #  same number of in-flight steps there as in the timed region and has reached its plateau when timing starts)
+        wpace = [] if (dev.type == "cuda" and not args.graph) else None
         for _ in range(args.warmup):
+            if wpace is not None and len(wpace) >= QUEUE_DEPTH:
+                wpace.pop(0).synchronize()
             last = run()
-            dsync()
-            log("warmup step done")
+            if wpace is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                wpace.append(ev)
+            else:
+                dsync()
+            log("warmup step launched")
         sync_all()
         if multi and last is not None and not args.graph:
             # fail fast, BEFORE anything is timed: a rank whose all-gathered bank differs would time a different problem
@@ -397,11 +407,31 @@ def main():
         sync_all()
         log("timing")
         state["timed"] = multi and not args.graph
+        dev_allocs0 = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) if dev.type == "cuda" else 0
+        reserved0 = torch.cuda.memory_reserved(dev) if dev.type == "cuda" else 0
         t0 = time.perf_counter()
+        # The host stays at most QUEUE_DEPTH steps ahead of the device (it waits for the event of step i - QUEUE_DEPTH before it
+        # launches step i; the device always has >= 2 steps queued, so it never idles).  Unbounded run-ahead makes the caching
+        # allocator grow for the whole timed region when the step uses side streams: a block whose tensor was `record_stream`-ed is
+        # reusable only once the recorded work has RUN, so a host K steps ahead needs K steps' worth of such blocks -- 2.4 GB per step
+        # here, one hipMalloc per ~1.5 steps inside the timed region (measured: 47.7 GB over 20 steps; single stream: 0), each a
+        # device-wide stall that costs 100+ ms on a box whose HBM has not been touched since boot.
+        pace = [] if (dev.type == "cuda" and not args.graph) else None
         for _ in range(args.steps):
+            if pace is not None and len(pace) >= QUEUE_DEPTH:
+                pace.pop(0).synchronize()
             last = run()
+            if pace is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                pace.append(ev)
         sync_all()
         elapsed = time.perf_counter() - t0
+        # hipMalloc calls of the caching allocator INSIDE the timed region: each one stalls the device for ~100 ms.  With the body on
+        # two streams the allocator keeps a pool per stream, and a step whose launches interleave differently from the warm-up's
+        # can still need fresh blocks -- the "slow mode" of the two-stream config-5 lines with --warmup 1
+        dev_allocs_timed = (int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0) if dev.type == "cuda" else 0
+        reserved_growth = (torch.cuda.memory_reserved(dev) - reserved0) if dev.type == "cuda" else 0
         state["timed"] = False
         trace_marker()
     if args.graph:
@@ -587,7 +617,9 @@ def main():
             line["hbm_gb"] = {"allocator_peak_reserved": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
                               "allocator_peak_allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                               "device_total": round(total_b / 2 ** 30, 1), "device_free_now": round(free_b / 2 ** 30, 1),
-                              "allocator_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0))}
+                              "allocator_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
+                              "device_allocs_in_timed_region": dev_allocs_timed,
+                              "reserved_growth_in_timed_region": round(reserved_growth / 2 ** 30, 2)}
         line.update(extras)
         if per_rank_ms is not None:
             line["ms_per_step_per_rank"] = per_rank_ms
@@ -704,6 +736,9 @@ def roofline_leg(step, dtype):
             "issued_tflop_per_step": round(sum(v[1] * mfma_issue_ratio(k)[0] for k, v in per.items()) / 1e12, 4),
             "other_variants": {k: {"launches": v[0], "ms_per_step": round(1e3 * v[2], 3), "algorithmic_TFLOP/s": rate(v)}
                                for k, v in per.items() if k != dom}}
+
+
+QUEUE_DEPTH = 2         # timed steps the host may run ahead of the device (see the timed loop)
 
 
 def trace_marker():

@@ -59,6 +59,17 @@ def test_bench_line_and_roofline_fields():
     # the bank is extractor output (the shop-side path, once, before the timed region), and its first rows were re-derived by the oracle
     assert d["bank"]["source"].startswith("extractor output") and d["bank"]["rows_this_rank"] == d["config"]["gallery"]
     assert d["value_clips1"] > 1.0 and d["full_forward_ms_per_clip"] > 0
+    # allocator activity inside the timed region is part of the line (a hipMalloc there stalls the device: DESIGN 3.4)
+    assert d["hbm_gb"]["device_allocs_in_timed_region"] >= 0 and d["hbm_gb"]["reserved_growth_in_timed_region"] >= 0.0
+
+
+def test_timed_region_does_not_grow_the_allocator():
+    """Default line (two body streams, side-stream tensors record_stream-ed): with the host held two steps ahead of the device and three
+    warm-up steps the caching allocator has reached its plateau before timing starts -- no hipMalloc inside the timed region (before
+    the pacing: 16 calls / +47.7 GB over 20 steps, and 100+ ms stalls in a box's first process)."""
+    d = run([sys.executable, "bench.py", "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-roofline", "--no-extras"])
+    assert d["hbm_gb"]["device_allocs_in_timed_region"] == 0 and d["hbm_gb"]["reserved_growth_in_timed_region"] == 0.0, d["hbm_gb"]
+    assert d["hbm_gb"]["allocator_retries"] == 0
 
 
 def test_bench_large_gallery_workload_c3():

@@ -19,12 +19,12 @@ cp /tmp/prof_$TAG/b_kernel_stats.csv $O/${TAG}_bench_kernel_stats_whole_run.csv 
 python3 $R/tools/kernel_trace_steps.py $(ls /tmp/prof_$TAG/b_kernel_trace.csv /tmp/prof_$TAG/*/b_kernel_trace.csv 2>/dev/null | head -1) > $O/${TAG}_bench_kernel_stats.csv 2> $O/${TAG}_bench_kernel_stats_region.txt
 # the same for the config-5 (fp16) step
 rm -rf /tmp/prof5_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5_$TAG -o b -- python3 $R/bench.py --dtype f16 --workload c5 --no-cpu-baseline --no-extras --steps 5 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof5_$TAG -o b -- python3 $R/bench.py --dtype f16 --workload c5 --no-cpu-baseline --no-extras --steps 5 --warmup 3 > /dev/null 2>&1
 python3 $R/tools/kernel_trace_steps.py $(ls /tmp/prof5_$TAG/b_kernel_trace.csv /tmp/prof5_$TAG/*/b_kernel_trace.csv 2>/dev/null | head -1) > $O/${TAG}_c5_kernel_stats.csv 2> $O/${TAG}_c5_kernel_stats_region.txt
 python3 $R/bench.py --workload c3 --no-roofline --cpu-runs 1 > $O/${TAG}_bench_c3.json 2>/dev/null
 python3 $R/bench.py --workload c4 --no-roofline --no-cpu-baseline > $O/${TAG}_bench_c4.json 2>/dev/null
 python3 $R/bench.py --dtype f16 --no-cpu-baseline > $O/${TAG}_bench_f16.json 2>/dev/null
-python3 $R/bench.py --dtype f16 --workload c5 --no-cpu-baseline --steps 5 --warmup 1 > $O/${TAG}_bench_c5_f16.json 2>/dev/null
+python3 $R/bench.py --dtype f16 --workload c5 --no-cpu-baseline --steps 5 --warmup 3 > $O/${TAG}_bench_c5_f16.json 2>/dev/null
 python3 $R/bench.py --graph --clips 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_graph.json 2>/dev/null
 python3 $R/bench.py --clips 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_clips1.json 2>/dev/null
 python3 $R/tools/heads_bench.py > $O/${TAG}_heads_bench.txt 2>/dev/null
