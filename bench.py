@@ -84,9 +84,10 @@ def parse():
     ap.add_argument("--two-streams", action="store_true",
                     help="fp16 path only (--dtype f16): run the body on two HIP streams like the fp32 path (1.5 %% faster; 91-106 GB of "
                          "allocator pools instead of 48).  The fp16 default is ONE stream.  The 205-220 ms lines once seen with two streams "
-                         "were hipMalloc stalls INSIDE the timed region (side-stream tensors are record_stream-ed, an unpaced host ran the "
+                         "were hipMalloc stalls INSIDE the timed region (side-stream tensors were record_stream-ed, an unpaced host ran the "
                          "whole timed region ahead, the caching allocator grew step by step; 100+ ms per call on a box whose HBM had not been "
-                         "touched since boot) -- the timed loop now keeps the host two steps ahead at most (DESIGN 3.4)")
+                         "touched since boot) -- the model no longer records streams and the timed loop keeps the host two steps ahead at "
+                         "most (DESIGN 3.4); two streams still want --warmup >= 3 (their own pools)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the clip the CPU baseline times (default: all)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed CPU runs after one warm-up; the minimum is reported")
     ap.add_argument("--graph", action="store_true",
@@ -411,11 +412,11 @@ def main():
         reserved0 = torch.cuda.memory_reserved(dev) if dev.type == "cuda" else 0
         t0 = time.perf_counter()
         # The host stays at most QUEUE_DEPTH steps ahead of the device (it waits for the event of step i - QUEUE_DEPTH before it
-        # launches step i; the device always has >= 2 steps queued, so it never idles).  Unbounded run-ahead makes the caching
-        # allocator grow for the whole timed region when the step uses side streams: a block whose tensor was `record_stream`-ed is
-        # reusable only once the recorded work has RUN, so a host K steps ahead needs K steps' worth of such blocks -- 2.4 GB per step
-        # here, one hipMalloc per ~1.5 steps inside the timed region (measured: 47.7 GB over 20 steps; single stream: 0), each a
-        # device-wide stall that costs 100+ ms on a box whose HBM has not been touched since boot.
+        # launches step i; the device always has >= 2 steps queued, so it never idles).  History: with `record_stream`-ed
+        # side-stream tensors in the model an unpaced host made the caching allocator grow for the whole timed region -- such a block
+        # is reusable only once the recorded work has RUN -- 2.4 GB and a hipMalloc per step (47.7 GB over 20 steps), each call a
+        # device-wide stall of 100+ ms on a box whose HBM has not been touched since boot.  The model no longer records streams
+        # (fork / join lifetimes: 0 allocations even unpaced); the pacing stays as the sane shape of a throughput loop.
         pace = [] if (dev.type == "cuda" and not args.graph) else None
         for _ in range(args.steps):
             if pace is not None and len(pace) >= QUEUE_DEPTH:
@@ -738,7 +739,7 @@ def roofline_leg(step, dtype):
                                for k, v in per.items() if k != dom}}
 
 
-QUEUE_DEPTH = 2         # timed steps the host may run ahead of the device (see the timed loop)
+QUEUE_DEPTH = int(os.environ.get("SEAM_BENCH_QUEUE_DEPTH", "2"))     # timed steps the host may run ahead of the device (see the timed loop)
 
 
 def trace_marker():

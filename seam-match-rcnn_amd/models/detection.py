@@ -261,7 +261,7 @@ class ResNet50Body(nn.Module):
 # The small pyramid levels (100^2 and below) cannot fill 256 CUs on their own; their FPN output convs and RPN-head launches run on
 # a side stream next to the 200^2 level's launches, whose blocks take the CUs they leave idle (SEAM_LEVEL_STREAMS=0: one stream).
 # Outputs are allocated on the calling stream and written through `out=`; tensors produced on one stream and read on the other are
-# registered with the caching allocator (record_stream).  Same kernels on the same data: results are bit-identical.
+# kept referenced until the join (fork / join lifetimes, see FPN.forward).  Same kernels on the same data: results are bit-identical.
 LEVEL_STREAMS = _os.environ.get("SEAM_LEVEL_STREAMS", "1") != "0"
 _SIDE_STREAMS = {}
 
@@ -317,20 +317,27 @@ class FeaturePyramidNetwork(nn.Module):
         outs = [torch.empty(tuple(f.shape[:3]) + (layer[i].K,), dtype=ydt, device=x3.device) for i, f in enumerate(feats)]
         pool = None
         last = ops.conv2d(x3, inner[3])
+        # Cross-stream lifetimes by fork / join, not by `record_stream`: a tensor of the calling stream that the side stream reads is
+        # kept referenced until `cur.wait_stream(side)` below (its block returns to the calling stream's pool, whose later work is
+        # ordered behind the join); a tensor the side stream allocates and the calling stream reads returns to the side stream's pool,
+        # and every side-stream phase of the model starts with `side.wait_stream(cur)`.  (`record_stream`-ed blocks are reusable only
+        # once the recorded work has RUN: a host that enqueues steps ahead of the device then needs a fresh set per step in flight --
+        # +2.4 GB and one hipMalloc per step at BASELINE config 2)
+        keep = []
         for i in (3, 2, 1, 0):
             if i < 3:
+                keep.append(last)
                 last = ops.conv2d_topdown(feats[i], inner[i], last)
             if i == 0:
                 ops.conv2d(last, layer[0], out=outs[0])
                 break
             side.wait_stream(cur)
-            last.record_stream(side)
             with torch.cuda.stream(side):
                 ops.conv2d(last, layer[i], out=outs[i])
                 if i == 3:
                     pool = ops.maxpool2d(outs[3], 1, 2, 0)      # LastLevelMaxPool
-                    pool.record_stream(cur)
         cur.wait_stream(side)
+        del keep
         od = OrderedDict((str(i), o) for i, o in enumerate(outs))
         od["pool"] = pool
         return od
@@ -402,8 +409,7 @@ class RPNHead(nn.Module):
         outs = [torch.empty(tuple(f.shape[:3]) + (heads.K,), dtype=torch.float32, device=f.device) for f in feats]
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for f, o in zip(feats[1:], outs[1:]):
-                f.record_stream(side)
+            for f, o in zip(feats[1:], outs[1:]):       # (the caller's `feats` outlive the join below: no record_stream, see FPN.forward)
                 ops.conv2d(ops.conv2d(f, conv, relu=True), heads, out=o, out_f32=True)
         ops.conv2d(ops.conv2d(feats[0], conv, relu=True), heads, out=outs[0], out_f32=True)
         cur.wait_stream(side)

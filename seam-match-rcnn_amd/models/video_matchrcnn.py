@@ -189,15 +189,10 @@ class TemporalRoIHeads(nn.Module):
             if det.LEVEL_STREAMS and roi_nhwc.is_cuda and roi_nhwc.shape[0] > 0:
                 cur, side = torch.cuda.current_stream(), det._side_stream(roi_nhwc.device)
                 side.wait_stream(cur)
-                roi_nhwc.record_stream(side)
-                labels = [r["labels"] for r in result]
-                for l in labels:
-                    l.record_stream(side)
-                with torch.cuda.stream(side):
+                labels = [r["labels"] for r in result]       # (`roi_nhwc` and the labels outlive the join at the end of this function:
+                with torch.cuda.stream(side):                #  fork / join lifetimes, no record_stream -- see det.FeaturePyramidNetwork.forward)
                     logits = self.mask_predictor(self.mask_head(roi_nhwc))
                     probs = det.maskrcnn_inference(logits, labels, self.num_classes)
-                    for pr in probs:
-                        pr.record_stream(cur)
             else:
                 logits = self.mask_predictor(self.mask_head(roi_nhwc))
                 probs = det.maskrcnn_inference(logits, [r["labels"] for r in result], self.num_classes)
